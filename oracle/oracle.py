@@ -1,0 +1,219 @@
+"""ctypes binding for the CPU oracle (oracle/ptk_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The shipped library never touches this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libptk_oracle.so")
+
+N_PLANES = 38
+PL_COL, PL_NORMAL, PL_ALB1, PL_ALB2, PL_WPOS, PL_DL, PL_SDV, PL_SD = 0, 3, 6, 9, 12, 15, 16, 32
+
+
+class Constants(C.Structure):
+    """Byte layout of the reference's struct Constants (headers/GLOBALS.h:80-94)."""
+    _fields_ = [
+        ("cam_pos", C.c_float * 3), ("cam_fwd", C.c_float * 3),
+        ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3),
+        ("max_angle", C.c_float), ("rand_samp", C.c_float),
+        ("num_shapes", C.c_int32), ("max_depth", C.c_int32),
+        ("res_v", C.c_int32), ("res_h", C.c_int32),
+        ("max_angle_v", C.c_float), ("max_angle_h", C.c_float), ("focal_length", C.c_float),
+        ("shapes", (C.c_int32 * 3) * 50),
+        ("attrs", C.c_float * 450),
+        ("mats", (C.c_float * 6) * 50),
+        ("imp", C.c_uint32 * 10),
+        ("num_imp", C.c_uint32),
+        ("want_features", C.c_uint32),
+    ]
+
+
+assert C.sizeof(Constants) == 3732
+
+
+class Sample(C.Structure):
+    _fields_ = [
+        ("xyz", C.c_float * 3), ("normal", C.c_float * 3), ("albedo1", C.c_float * 3),
+        ("albedo2", C.c_float * 3), ("world_pos", C.c_float * 3),
+        ("direct_light", C.c_float), ("rays_sent", C.c_uint32),
+    ]
+
+
+assert C.sizeof(Sample) == 68
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("n_mats", C.c_int), ("n_shapes", C.c_int), ("n_imp", C.c_int),
+        ("mats", (C.c_float * 6) * 64),
+        ("shape_type", C.c_int * 64), ("shape_mat", C.c_int * 64),
+        ("shape_pos", (C.c_float * 3) * 64),
+        ("sphere_r", C.c_float * 64),
+        ("box_min", (C.c_float * 3) * 64), ("box_max", (C.c_float * 3) * 64),
+        ("box_rot", (C.c_float * 3) * 64), ("box_q", (C.c_float * 4) * 64),
+        ("imp", C.c_int * 64),
+        ("cam_pos", C.c_float * 3), ("cam_fwd", C.c_float * 3),
+        ("cam_up", C.c_float * 3), ("cam_right", C.c_float * 3),
+        ("vfov", C.c_float), ("hfov", C.c_float), ("focal_len", C.c_float),
+        ("exposure", C.c_float), ("gamma", C.c_float),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few seconds)."""
+    src = os.path.join(_HERE, "ptk_oracle.c")
+    hdr = os.path.join(_HERE, "ptk_oracle.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libptk_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_load_scene.argtypes = [C.c_char_p, C.POINTER(Scene)]
+        L.orc_load_scene.restype = C.c_int
+        L.orc_build_constants.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_int, C.POINTER(Constants)]
+        L.orc_build_constants.restype = None
+        L.orc_seed_stream.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_int64)]
+        L.orc_seed_stream.restype = None
+        L.orc_rand_between.argtypes = [C.POINTER(C.c_int64), C.c_float, C.c_float]
+        L.orc_rand_between.restype = C.c_float
+        L.orc_render_sample.argtypes = [C.POINTER(Constants), C.c_int, C.c_int, C.c_int64,
+                                        C.c_int64, C.POINTER(Sample)]
+        L.orc_render_sample.restype = None
+        L.orc_render.argtypes = [C.POINTER(Constants), fp, C.c_int, C.POINTER(C.c_int),
+                                 C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
+        L.orc_render.restype = None
+        L.orc_auto_exposure.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_double)]
+        L.orc_auto_exposure.restype = C.c_float
+        L.orc_forward_prop.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_int]
+        L.orc_forward_prop.restype = None
+        L.orc_filter.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int]
+        L.orc_filter.restype = None
+        L.orc_filter_variant.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp,
+                                         C.c_int]
+        L.orc_filter_variant.restype = None
+        L.orc_load_weights.argtypes = [C.c_char_p, fp, fp, fp]
+        L.orc_load_weights.restype = C.c_int
+        L.orc_tonemap8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                   C.POINTER(C.c_uint8)]
+        L.orc_tonemap8.restype = None
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def load_scene(path):
+    s = Scene()
+    rc = lib().orc_load_scene(os.fsencode(path), C.byref(s))
+    if rc != 0:
+        raise IOError("cannot load scene %s (rc=%d)" % (path, rc))
+    return s
+
+
+def build_constants(scene, width, height, max_depth=4, rand_samp=0.005, denoising=True):
+    c = Constants()
+    lib().orc_build_constants(C.byref(scene), width, height, max_depth,
+                              C.c_float(rand_samp), int(bool(denoising)), C.byref(c))
+    return c
+
+
+def seed_stream(glo, n):
+    """Advance the global seed state n steps; returns (n,2) int64 pixel seeds and the new state."""
+    st = (C.c_uint64 * 2)(glo[0], glo[1])
+    out = np.empty((n, 2), dtype=np.int64)
+    lib().orc_seed_stream(st, n, out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out, (int(st[0]), int(st[1]))
+
+
+def rand_stream(s1, s2, count, lo=0.0, hi=1.0):
+    """count successive randBetween(lo, hi) draws from one pixel seed."""
+    st = (C.c_int64 * 2)(s1, s2)
+    out = np.empty(count, dtype=np.float32)
+    f = lib().orc_rand_between
+    for i in range(count):
+        out[i] = f(st, C.c_float(lo), C.c_float(hi))
+    return out, (int(st[0]), int(st[1]))
+
+
+def render_sample(consts, row, col, s1, s2):
+    s = Sample()
+    lib().orc_render_sample(C.byref(consts), row, col, s1, s2, C.byref(s))
+    return s
+
+
+def new_accumulators(width, height):
+    return np.zeros((N_PLANES, height * width), dtype=np.float32)
+
+
+def render(consts, acc, spp, sample_count, glo, threads=1):
+    """Run spp accumulate passes.  Returns (sample_count, glo, rays_last_pass)."""
+    sc = C.c_int(sample_count)
+    st = (C.c_uint64 * 2)(glo[0], glo[1])
+    rays = C.c_uint64(0)
+    lib().orc_render(C.byref(consts), _fp(acc), spp, C.byref(sc), st, threads, C.byref(rays))
+    return sc.value, (int(st[0]), int(st[1])), int(rays.value)
+
+
+def auto_exposure(acc, width, height, sample_count, formula=0):
+    raw = C.c_double(0)
+    e = lib().orc_auto_exposure(_fp(acc), width, height, sample_count, formula, C.byref(raw))
+    return float(e), float(raw.value)
+
+
+def load_weights(path):
+    w12 = np.zeros(360, np.float32)
+    w23 = np.zeros(100, np.float32)
+    w34 = np.zeros(70, np.float32)
+    rc = lib().orc_load_weights(os.fsencode(path), _fp(w12), _fp(w23), _fp(w34))
+    if rc != 0:
+        raise IOError("cannot load weights %s (rc=%d)" % (path, rc))
+    return w12, w23, w34
+
+
+def forward_prop(acc, width, height, sample_count, weights, threads=1):
+    P = width * height
+    feats = np.zeros((P, 36), np.float32)
+    var = np.zeros((P, 7), np.float32)
+    w12, w23, w34 = weights
+    lib().orc_forward_prop(_fp(acc), width, height, sample_count, _fp(w12), _fp(w23), _fp(w34),
+                           _fp(feats), _fp(var), threads)
+    return feats, var
+
+
+def filter(acc, variances, width, height, sample_count, n=1, threads=1, colour_variant=0):
+    P = width * height
+    den = np.zeros((P, 3), np.float32)
+    wc = np.zeros(P, np.float32)
+    lib().orc_filter_variant(_fp(acc), _fp(variances), width, height, sample_count, n,
+                             colour_variant, _fp(den), _fp(wc), threads)
+    return den, wc
+
+
+def tonemap8(acc, width, height, sample_count, exposure, gamma):
+    out = np.zeros((height, width, 3), np.uint8)
+    lib().orc_tonemap8(_fp(acc), width, height, sample_count, C.c_float(exposure),
+                       C.c_float(gamma), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
