@@ -1,0 +1,200 @@
+/*
+ * ptk.h -- C ABI of libptk, the MI355X (gfx950) implementation of the
+ * Path-Tracer per-frame hot path: path trace + accumulate, exposure reduce,
+ * denoiser inference (feature statistics -> MLP -> cross-bilateral filter).
+ *
+ * The reference has no FFI; its GPU seam is backend slot 2 of four switch
+ * dispatchers (headers/Renderers.h:31-60,72-101, Denoiser.cpp:9-35,
+ * headers/DenoiserNN.h:103-131), which forward to void(void) functions in
+ * three namespaces (headers/CUDAHeader.h:5-52) that exchange data through
+ * globals (headers/GLOBALS.h:15-76).  Each entry point below names the
+ * reference function(s) it replaces; the data that crossed through globals
+ * crosses here through explicit pointers.
+ *
+ * Conventions: every function returns PTK_OK (0) or a negative PTK_ERR_* code
+ * and leaves a message for ptk_last_error() (thread-local).  Pointers are host
+ * memory unless the name ends in _d.  A context is bound to one GPU and is not
+ * thread-safe; calls on one context execute in issue order.  Images are
+ * row-major with row 0 at the BOTTOM (the reference's convention,
+ * Renderers.cpp:67, PT.cpp:487).
+ */
+#ifndef PTK_H
+#define PTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTK_OK 0
+#define PTK_ERR_ARG (-1)    /* bad argument (null pointer, size, range) */
+#define PTK_ERR_HIP (-2)    /* a HIP runtime call failed */
+#define PTK_ERR_STATE (-3)  /* call order violated (e.g. render before set_constants) */
+#define PTK_ERR_NOMEM (-4)  /* host or device allocation failed */
+
+/* Scene POD handed to ptk_set_constants: byte-for-byte the reference's
+ * struct Constants (headers/GLOBALS.h:80-94), so a host that already fills
+ * that struct (Renderers.cpp:1051-1149) passes its address unchanged. */
+#define PTK_MAX_SHAPES 50
+#define PTK_MAX_ATTRS 450
+#define PTK_MAX_MATS 50
+#define PTK_MAX_IMPORTANT 10
+#define PTK_MAX_DEPTH 12
+typedef struct ptk_constants {
+    float cam_pos[3], cam_forward[3], cam_right[3], cam_up[3];
+    float max_angle, rand_samp;
+    int32_t num_shapes, max_depth;
+    int32_t res_v, res_h;
+    float max_angle_v, max_angle_h, focal_length;
+    int32_t shapes[PTK_MAX_SHAPES][3];   /* {type 0 sphere / 1 box, material, attr offset} */
+    float obj_attributes[PTK_MAX_ATTRS]; /* sphere: centre,r; box: centre, lo, hi, quat w,x,y,z */
+    float mat_list[PTK_MAX_MATS][6];     /* r,g,b, blur, refractive index, type 0..3 */
+    uint32_t important_shapes[PTK_MAX_IMPORTANT];
+    uint32_t num_important_shapes;
+    uint32_t get_denoiser_inf;
+} ptk_constants;
+#define PTK_CONSTANTS_BYTES 3732
+
+/* Accumulator planes held in HBM, plane-major: plane p of pixel i is at
+ * base[p * P + i], P = width * height. */
+enum {
+    PTK_PL_COL = 0,     /* 3: sum of radiance                      (preScreen)   */
+    PTK_PL_NORMAL = 3,  /* 3: sum of first-hit normals             (normal)      */
+    PTK_PL_ALB1 = 6,    /* 3: sum of first-hit albedo              (albedo1)     */
+    PTK_PL_ALB2 = 9,    /* 3: sum of second-hit albedo             (albedo2)     */
+    PTK_PL_WPOS = 12,   /* 3: sum of first-hit positions           (worldPos)    */
+    PTK_PL_DL = 15,     /* 1: sum of direct-light fractions        (directLight) */
+    PTK_PL_SDV = 16,    /* 16: running squared deviations (stdDevVecs, 5x3 + 1)  */
+    PTK_PL_SD = 32,     /* 6: stdDev[6] as of the last sample                    */
+    PTK_N_PLANES = 38
+};
+
+/* seed_mode of ptk_render */
+#define PTK_SEED_REFERENCE 0 /* host-sequential global seed stream (Renderers.cpp:832-838) */
+#define PTK_SEED_COUNTER 1   /* device counter-based seeds: hash(pixel, sample, stream) */
+
+/* math mode of ptk_set_math_mode */
+#define PTK_MATH_EXACT 0 /* IEEE divide/sqrt, no FMA contraction, reference operation order */
+#define PTK_MATH_FAST 1  /* reciprocal-based slabs, FMA contraction; statistically equivalent */
+
+/* formula of ptk_auto_exposure */
+#define PTK_EXPOSURE_CPU 0   /* sum * 9.6f / xRes * yRes * spp, as written (Renderers.cpp:1158) */
+#define PTK_EXPOSURE_SKEPU 1 /* 9.6f * sum / P * spp, as written (Renderers.cpp:1192) */
+#define PTK_EXPOSURE_MEAN 2  /* 9.6 * mean luminance per sample */
+
+typedef struct ptk_ctx ptk_ctx;
+
+/* Device time of the most recent call of each kind, from HIP events on the
+ * context's stream (replaces the chrono globals renderTime / exposureTime /
+ * denoiseTime, headers/Renderers.h:33,59,74,100, Denoiser.cpp:5,37). */
+typedef struct ptk_times {
+    double render_ms;        /* path-trace kernels of the last ptk_render            */
+    double seed_ms;          /* host seed generation + upload (seed mode 0 only)     */
+    double exposure_ms;      /* reduce kernel of the last ptk_auto_exposure          */
+    double features_ms;      /* feature + MLP kernel of the last ptk_denoise         */
+    double filter_ms;        /* filter kernel of the last ptk_denoise                */
+    double denoise_ms;       /* features_ms + filter_ms (or the fused kernel)        */
+    uint64_t render_samples; /* width*height*spp of the last ptk_render              */
+    uint64_t render_rays;    /* bounce rays traced by the last ptk_render            */
+} ptk_times;
+
+/* Replaces CUDADenoiser::InitBuffers / CUDADenoiserNN::InitBuffers
+ * (CUDADenoiser.cu:184-189, CUDADenoiserNN.cu:614-632) and the allocation
+ * half of CUDARender::UpdateConstants (CUDARender.cu:933-957).  Binds the
+ * context to GPU `device`; buffers are sized on ptk_set_constants. */
+int ptk_create(int device, ptk_ctx** out);
+
+/* Replaces the three FreeBuffers (CUDADenoiser.cu:190-195,
+ * CUDADenoiserNN.cu:634-646). */
+int ptk_destroy(ptk_ctx* ctx);
+
+/* Message of the calling thread's most recent failed call ("" if none). */
+const char* ptk_last_error(void);
+
+/* Replaces CUDARender::UpdateConstants (CUDARender.cu:933-957): takes the
+ * 3732-byte scene POD, validates it (the reference does not: shape, material
+ * and attribute indices are range-checked here and rejected with
+ * PTK_ERR_ARG), compiles it for the device and (re)allocates the planes when
+ * the resolution changed.  Resets the accumulators, as the reference's
+ * RefreshScreen does (PT.cpp:159-169).  want_denoise_features overrides the
+ * POD's get_denoiser_inf when >= 0. */
+int ptk_set_constants(ptk_ctx* ctx, const void* constants, size_t nbytes,
+                      int want_denoise_features);
+
+/* The zeroing half of PT::RefreshScreen (PT.cpp:159-169): sampleCount = 0 and
+ * all planes cleared. */
+int ptk_reset_accumulators(ptk_ctx* ctx);
+
+/* PTK_MATH_EXACT (default) or PTK_MATH_FAST for subsequent ptk_render calls. */
+int ptk_set_math_mode(ptk_ctx* ctx, int mode);
+
+/* Stream id mixed into PTK_SEED_COUNTER seeds (one per GPU when samples are
+ * split across ranks).  Default 0. */
+int ptk_set_stream_id(ptk_ctx* ctx, uint64_t stream_id);
+
+/* Replaces `spp` calls of CUDARender::render (CUDARender.cu:857-931), with
+ * the host accumulate loop (886-929, identical to CPURender's,
+ * Renderers.cpp:845-888) fused into the kernel: each pass increments
+ * sampleCount, traces one path per pixel and updates all planes.
+ * seed_mode PTK_SEED_REFERENCE advances glo_seed exactly spp*width*height
+ * steps of the reference's recurrence (in-out, must be non-null);
+ * PTK_SEED_COUNTER ignores glo_seed.  rays_out (optional) receives the bounce
+ * rays of the whole call (the reference's rayCount for spp == 1). */
+int ptk_render(ptk_ctx* ctx, int spp, int seed_mode, uint64_t glo_seed[2], uint64_t* rays_out);
+
+/* Hands the accumulators back in the layout of the reference's globals
+ * (headers/GLOBALS.h:45-76) so a host can refill them: interleaved xyz per
+ * pixel for the five vec3 screens, one float per pixel for directLight's x,
+ * six floats per pixel for DenoisingInf::stdDev.  Any pointer may be null. */
+int ptk_read_accumulators(ptk_ctx* ctx, float* pre_screen_3p, float* normal_3p,
+                          float* albedo1_3p, float* albedo2_3p, float* direct_light_1p,
+                          float* world_pos_3p, float* std_dev_6p, int* sample_count);
+
+/* Raw plane access (plane-major floats, n_planes * P values): used to seed
+ * synthetic accumulators, to checkpoint, and by multi-GPU reduction. */
+int ptk_read_planes(ptk_ctx* ctx, int first_plane, int n_planes, float* out);
+int ptk_write_planes(ptk_ctx* ctx, int first_plane, int n_planes, const float* in,
+                     int sample_count);
+
+/* Device address of plane 0 and the per-plane pixel count, for collectives
+ * that reduce the planes in place (the planes are one contiguous allocation
+ * of PTK_N_PLANES * P floats). */
+int ptk_planes_device(ptk_ctx* ctx, float** base_d, size_t* pixels_per_plane);
+int ptk_get_sample_count(ptk_ctx* ctx, int* sample_count);
+int ptk_set_sample_count(ptk_ctx* ctx, int sample_count);
+
+/* Recomputes planes PTK_PL_SD from sum and sum-of-squares style planes after a
+ * cross-GPU reduction: stdDev[k] = sum_c sdv[k][c] / sample_count. */
+int ptk_refresh_std_dev(ptk_ctx* ctx);
+
+/* Replaces CUDARender::CUDAAutoExp (CUDARender.cu:1068-1094) and mirrors
+ * Renderers::CPUAutoExp / SkePUAutoExp (Renderers.cpp:1151-1159, 1174-1193):
+ * luminance map + sum on the device.  raw_sum (optional) receives the
+ * unscaled sum of per-pixel luminance in double. */
+int ptk_auto_exposure(ptk_ctx* ctx, int formula, float* exposure, double* raw_sum);
+
+/* Replaces CUDADenoiserNN::ForwardProp (CUDADenoiserNN.cu:297-368) followed by
+ * CUDADenoiser::denoise (CUDADenoiser.cu:123-182), with the arithmetic of the
+ * sequential copies (DenoiserNN.cpp:12-301, Denoiser.cpp:222-355): 36
+ * neighbourhood features -> 36-10-10-7 MLP (weights in the file order of
+ * DenoiserNN.cpp:1625-1663: w12[36*node+input], w23[10*node+input],
+ * w34[10*node+input]) -> (2N+1)^2 clamp-to-edge cross-bilateral filter.
+ * variant 0 = separate feature and filter kernels, 1 = fused kernel.
+ * Outputs (all optional): denoised rgb interleaved (3P), wcSum (P),
+ * variances (7P, pixel-major), features (36P, pixel-major; variant 0 only). */
+int ptk_denoise(ptk_ctx* ctx, const float w12[360], const float w23[100], const float w34[70],
+                int n, int variant, float* denoised_3p, float* wc_sum_p, float* variances_7p,
+                float* features_36p);
+
+/* Replaces the chrono globals; see ptk_times. */
+int ptk_timing(ptk_ctx* ctx, ptk_times* out);
+
+/* Blocks until all work issued on the context has finished. */
+int ptk_synchronize(ptk_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTK_H */

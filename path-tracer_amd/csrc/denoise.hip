@@ -1,0 +1,408 @@
+// denoise.hip -- denoiser inference: neighbourhood feature statistics + MLP
+// (DenoiserNN.cpp:12-301) and the cross-bilateral filter (Denoiser.cpp:222-355).
+//
+// Both passes are 16x16-output LDS-tiled stencils with clamp-to-edge halos.
+// Discrete parts (Sobel order, the "median getter" procedure, tie-breaking)
+// consume bit-exact primary features; the smooth parts (7x7 variance, mean
+// deviation, MLP, Gaussian weights) are evaluated in fp32 with FMA and the
+// hardware exp/log, and are compared with the reference within a tolerance.
+#include <hip/hip_runtime.h>
+
+#include "ptk_dev.h"
+
+#define DEV __device__ __forceinline__
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int FH = 3;                  // feature halo (7x7 window)
+constexpr int FT = TILE + 2 * FH;      // 22
+constexpr int FT_PITCH = FT + 1;       // 23: odd pitch spreads rows over LDS banks
+
+DEV int clampi(int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); }
+
+DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+DEV float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// x / n, bit-identical to the IEEE quotient: an exact reciprocal multiply when
+// n is a power of two, the correctly rounded division otherwise.
+struct DivN {
+    float n, inv;
+    bool pow2;
+    DEV float operator()(float x) const { return pow2 ? x * inv : x / n; }
+};
+DEV DivN make_divn(float n)
+{
+    DivN d;
+    d.n = n;
+    int bits = __float_as_int(n);
+    d.pow2 = (bits & 0x007fffff) == 0;
+    d.inv = 1.0f / n;
+    return d;
+}
+
+// The reference's "median getter" procedure (DenoiserNN.cpp:190-256), literal,
+// on registers.  It is not a median.
+#pragma clang fp contract(off)
+DEV void mg_insert_pass1(float v, float (&m)[5])
+{
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (!done) {
+            if (v > m[k]) {
+                if (k == 4) { float t = m[4]; m[3] = t; m[2] = t; m[1] = t; m[0] = t; m[4] = v; }
+            } else if (k > 0) {
+                m[k - 1] = v;
+                done = true;
+            }
+        }
+    }
+}
+DEV void mg_insert_pass2(float v, float (&m)[5])
+{
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (!done) {
+            if (v > m[k]) {
+                if (k == 4) { float t = m[4]; m[3] = t; m[2] = t; m[1] = t; m[0] = t; m[4] = v; }
+            } else if (k > 0) {
+                float t = m[k];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (q < k) m[q] = t;
+                m[k] = v;
+                done = true;
+            }
+        }
+    }
+}
+DEV float mad_procedure(float (&v)[9])
+{
+    float m[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 9; i++) mg_insert_pass1(v[i], m);
+    float m0 = m[0];
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] = __builtin_fabsf(v[i] - m0);
+#pragma unroll
+    for (int k = 0; k < 5; k++) m[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) mg_insert_pass2(v[i], m);
+    return m[0];
+}
+
+// Primary feature of one pixel (DenoiserNN.cpp:16-36): three separate
+// quotients summed in order, bit-exact.
+DEV float primary3(const float* __restrict__ p, size_t P, size_t i, float three_n)
+{
+    float v = 0.0f;
+    v += p[i] / three_n;
+    v += p[P + i] / three_n;
+    v += p[2 * P + i] / three_n;
+    return v;
+}
+#pragma clang fp contract(fast)
+
+// Weighted sum over `n` inputs with wave-uniform weights (scalar loads).
+template <int N>
+DEV float dot_w(const float (&x)[N], const __attribute__((address_space(4))) float* w)
+{
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++) a = __builtin_fmaf(x[i], w[i], a);
+    return a;
+}
+
+DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
+
+// 36 features + MLP for the pixel at tile coordinates (ly, lx) of an LDS tile
+// of primaries `t` laid out [5][FT][FT_PITCH].
+DEV void features_and_mlp(const float* t, int ly, int lx, const float* sd5, float inv_spp,
+                          const __attribute__((address_space(4))) float* w, float (&f)[36],
+                          float (&var)[7])
+{
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const float* tk = t + k * FT * FT_PITCH;
+        f[k] = tk[(ly + FH) * FT_PITCH + lx + FH];
+        f[5 + k] = sd5[k];
+
+        // 7x7 mean: the reference adds q/49 term by term in row-major order
+        float mean7 = 0.0f;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+#pragma unroll
+                for (int i = 0; i < 7; i++) mean7 += tk[(ly + j) * FT_PITCH + lx + i] / 49.0f;
+        }
+        // 7x7 standard deviation about that mean
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                float d = tk[(ly + j) * FT_PITCH + lx + i] - mean7;
+                ss = __builtin_fmaf(d, d, ss);
+            }
+        f[10 + k] = mean7;
+        f[15 + k] = __builtin_sqrtf(ss * (1.0f / 49.0f));
+
+        float win[9];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) win[j * 3 + i] = tk[(ly + FH - 1 + j) * FT_PITCH + lx + FH - 1 + i];
+        float gx, gy, mean3 = 0.0f;
+        {
+#pragma clang fp contract(off)
+            // Sobel sums in the reference's accumulation order; zero taps add +-0
+            gx = 0.0f; gx += win[0]; gx += 2.0f * win[1]; gx += win[2];
+            gx += 0.0f * win[3]; gx += 0.0f * win[4]; gx += 0.0f * win[5];
+            gx += -1.0f * win[6]; gx += -2.0f * win[7]; gx += -1.0f * win[8];
+            gy = 0.0f; gy += win[0]; gy += 0.0f * win[1]; gy += -1.0f * win[2];
+            gy += 2.0f * win[3]; gy += 0.0f * win[4]; gy += -2.0f * win[5];
+            gy += win[6]; gy += 0.0f * win[7]; gy += -1.0f * win[8];
+            f[20 + k] = __builtin_sqrtf(gx * gx + gy * gy);
+#pragma unroll
+            for (int i = 0; i < 9; i++) mean3 += win[i] / 9.0f;
+        }
+        float md = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 9; i++) md += __builtin_fabsf(win[i] - mean3) * (1.0f / 9.0f);
+        f[25 + k] = md;
+        f[30 + k] = mad_procedure(win);
+    }
+    f[35] = inv_spp;
+
+    float l2[10], l3[10];
+#pragma unroll
+    for (int nd = 0; nd < 10; nd++) l2[nd] = sigmoid(dot_w<36>(f, w + 36 * nd));
+#pragma unroll
+    for (int nd = 0; nd < 10; nd++) l3[nd] = sigmoid(dot_w<10>(l2, w + 360 + 10 * nd));
+#pragma unroll
+    for (int nd = 0; nd < 7; nd++) var[nd] = softplus(dot_w<10>(l3, w + 460 + 10 * nd));
+}
+
+// Loads the 22x22 tile of primaries around the block's 16x16 outputs.
+DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int bx, int by,
+                           float n, float* t)
+{
+    const float three_n = 3.0f * n;
+    for (int e = threadIdx.x; e < FT * FT; e += blockDim.x) {
+        int ty = e / FT, tx = e - ty * FT;
+        int gy = clampi(by * TILE + ty - FH, H), gx = clampi(bx * TILE + tx - FH, W);
+        size_t gi = (size_t)gy * W + gx;
+        int o = ty * FT_PITCH + tx;
+        t[0 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_NORMAL * P, P, gi, three_n);
+        t[1 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_ALB1 * P, P, gi, three_n);
+        t[2 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_ALB2 * P, P, gi, three_n);
+        t[3 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_WPOS * P, P, gi, three_n);
+        t[4 * FT * FT_PITCH + o] = planes[PTK_PL_DL * P + gi] / n;
+    }
+}
+
+__global__ __launch_bounds__(256) void features_mlp_kernel(DenoiseArgs a)
+{
+    __shared__ float tile[5 * FT * FT_PITCH];
+    const int W = a.width, H = a.height;
+    const size_t P = (size_t)W * H;
+    const float n = (float)a.sample_count;
+    load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, tile);
+    __syncthreads();
+
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = blockIdx.x * TILE + lx, y = blockIdx.y * TILE + ly;
+    if (x >= W || y >= H) return;
+    const size_t idx = (size_t)y * W + x;
+    float sd5[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) sd5[k] = a.planes[(size_t)(PTK_PL_SD + 1 + k) * P + idx];
+    float f[36], var[7];
+    const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
+    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, f, var);
+#pragma unroll
+    for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
+    if (a.features) {
+#pragma unroll
+        for (int k = 0; k < 36; k++) a.features[(size_t)k * P + idx] = f[k];
+    }
+}
+
+// ---- filter ---------------------------------------------------------------
+
+constexpr int FV = 17;  // per tile element: col, normal, alb1, alb2, wpos (/n), dl/n, sd0
+
+DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int H, int bx, int by,
+                          int N, float nf, float* t)
+{
+    const int S = TILE + 2 * N;
+    const int SS = S * S;
+    const DivN dv = make_divn(nf);
+    for (int e = threadIdx.x; e < SS; e += blockDim.x) {
+        int ty = e / S, tx = e - ty * S;
+        int gy = clampi(by * TILE + ty - N, H), gx = clampi(bx * TILE + tx - N, W);
+        size_t gi = (size_t)gy * W + gx;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k * SS + e] = dv(planes[(size_t)k * P + gi]);
+        t[16 * SS + e] = planes[(size_t)PTK_PL_SD * P + gi];
+    }
+}
+
+// Filter taps for the pixel at tile coordinates (ly, lx); sd/var are the
+// centre pixel's.  Returns sum(w*col) and sum(w).
+DEV void filter_pixel(const float* t, int S, int ly, int lx, int N, const float* sd, const float* var,
+                      float (&wsum)[3], float& wc)
+{
+    const int SS = S * S;
+    const int ce = (ly + N) * S + lx + N;
+    float pv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pv[k] = t[k * SS + ce];
+    const float sd0 = sd[0];
+    const float inv_idx = fast_rcp(2.0f * var[0]);
+    const float col_scale = 2.0f * var[1];
+    const float inv_nrm = fast_rcp(sd[1] * 2.0f * var[2] + 0.000001f);
+    const float inv_a1 = fast_rcp(sd[2] * 2.0f * var[3] + 0.000001f);
+    const float inv_a2 = fast_rcp(sd[3] * 2.0f * var[4] + 0.000001f);
+    const float inv_wp = fast_rcp(2.0f * sd[4] * var[5] + 0.000001f);
+    const float inv_dl = fast_rcp(sd[5] * 2.0f * var[6] + 0.000001f);
+    wsum[0] = wsum[1] = wsum[2] = 0.0f;
+    wc = 0.0f;
+    for (int j = -N; j <= N; j++) {
+        for (int i = -N; i <= N; i++) {
+            const int e = ce + j * S + i;
+            float q[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) q[k] = t[k * SS + e];
+            const float sd0q = t[16 * SS + e];
+            float d2[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                float dx = q[3 * k] - pv[3 * k], dy = q[3 * k + 1] - pv[3 * k + 1],
+                      dz = q[3 * k + 2] - pv[3 * k + 2];
+                d2[k] = dx * dx + dy * dy + dz * dz;
+            }
+            float ddl = q[15] - pv[15];
+            float arg = (float)(j * j + i * i) * inv_idx;
+            arg += d2[0] * fast_rcp((sd0 + sd0q) * col_scale + 0.000001f);
+            arg += d2[1] * inv_nrm;
+            arg += d2[2] * inv_a1;
+            arg += d2[3] * inv_a2;
+            arg += d2[4] * inv_wp;
+            arg += ddl * ddl * inv_dl;
+            float w = fast_exp(-arg);
+            wsum[0] += q[0] * w;
+            wsum[1] += q[1] * w;
+            wsum[2] += q[2] * w;
+            wc += w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void filter_kernel(DenoiseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float ftile[];
+    const int W = a.width, H = a.height, N = a.n;
+    const size_t P = (size_t)W * H;
+    const int S = TILE + 2 * N;
+    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, (float)a.sample_count, ftile);
+    __syncthreads();
+
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = blockIdx.x * TILE + lx, y = blockIdx.y * TILE + ly;
+    if (x >= W || y >= H) return;
+    const size_t idx = (size_t)y * W + x;
+    float sd[6], var[7];
+#pragma unroll
+    for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
+#pragma unroll
+    for (int k = 0; k < 7; k++) var[k] = a.variances[(size_t)k * P + idx];
+    float wsum[3], wc;
+    filter_pixel(ftile, S, ly, lx, N, sd, var, wsum, wc);
+    const float inv = 1.0f / wc;
+    a.denoised[idx] = wsum[0] * inv;
+    a.denoised[P + idx] = wsum[1] * inv;
+    a.denoised[2 * P + idx] = wsum[2] * inv;
+    a.wc_sum[idx] = wc;
+}
+
+// ---- fused: features + MLP for the centre pixel, then the filter, one launch.
+__global__ __launch_bounds__(256) void denoise_fused_kernel(DenoiseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int W = a.width, H = a.height, N = a.n;
+    const size_t P = (size_t)W * H;
+    const int S = TILE + 2 * N;
+    float* ptile = smem;
+    float* ftile = smem + 5 * FT * FT_PITCH;
+    const float n = (float)a.sample_count;
+    load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, ptile);
+    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, n, ftile);
+    __syncthreads();
+
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = blockIdx.x * TILE + lx, y = blockIdx.y * TILE + ly;
+    if (x >= W || y >= H) return;
+    const size_t idx = (size_t)y * W + x;
+    float sd[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
+    float f[36], var[7];
+    const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
+    features_and_mlp(ptile, ly, lx, sd + 1, 1.0f / n, w, f, var);
+#pragma unroll
+    for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
+    float wsum[3], wc;
+    filter_pixel(ftile, S, ly, lx, N, sd, var, wsum, wc);
+    const float inv = 1.0f / wc;
+    a.denoised[idx] = wsum[0] * inv;
+    a.denoised[P + idx] = wsum[1] * inv;
+    a.denoised[2 * P + idx] = wsum[2] * inv;
+    a.wc_sum[idx] = wc;
+}
+
+size_t filter_lds_bytes(int N)
+{
+    size_t S = TILE + 2 * (size_t)N;
+    return S * S * FV * sizeof(float);
+}
+
+}  // namespace
+
+hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
+{
+    dim3 grid((a.width + TILE - 1) / TILE, (a.height + TILE - 1) / TILE);
+    hipLaunchKernelGGL(features_mlp_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
+{
+    dim3 grid((a.width + TILE - 1) / TILE, (a.height + TILE - 1) / TILE);
+    size_t lds = filter_lds_bytes(a.n);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)filter_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(filter_kernel, grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream)
+{
+    dim3 grid((a.width + TILE - 1) / TILE, (a.height + TILE - 1) / TILE);
+    size_t lds = filter_lds_bytes(a.n) + 5 * FT * FT_PITCH * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)denoise_fused_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(denoise_fused_kernel, grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}

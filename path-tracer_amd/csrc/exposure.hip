@@ -1,0 +1,124 @@
+// exposure.hip -- luminance map + sum over the colour planes
+// (Renderers.cpp:1151-1159 and 1174-1193), and the stdDev refresh used after
+// a cross-GPU reduction.
+//
+// HBM-bound: 12 bytes read per pixel, one double atomic per workgroup.  Each
+// lane sums float4 slices in fp32 (the per-pixel term is the reference's fp32
+// expression), widens to double, and the wave reduces with DPP row operations.
+#include <hip/hip_runtime.h>
+
+#include "ptk_dev.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+
+// Sum over the 64 lanes of a wave; the result is valid in every lane.
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int FORMULA>
+__device__ __forceinline__ float luminance(float r, float g, float b)
+{
+    if (FORMULA == 1)  // SkePUExposureFuncCalc: two of the products are double
+        return (float)((double)(0.2125f * r) + 0.7154 * (double)g + 0.0721 * (double)b);
+    return 0.2125f * r + 0.7154f * g + 0.0721f * b;
+}
+
+template <int FORMULA>
+__global__ __launch_bounds__(256) void exposure_kernel(const float* __restrict__ planes, size_t P,
+                                                       double* __restrict__ sum)
+{
+    const float* pr = planes;
+    const float* pg = planes + P;
+    const float* pb = planes + 2 * P;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    double part = 0.0;
+    if ((P & 3) == 0) {
+        const size_t n4 = P >> 2;
+        const float4* r4 = (const float4*)pr;
+        const float4* g4 = (const float4*)pg;
+        const float4* b4 = (const float4*)pb;
+        float acc = 0.0f;
+        int run = 0;
+        for (size_t i = tid; i < n4; i += nthreads) {
+            float4 r = r4[i], g = g4[i], b = b4[i];
+            acc += (luminance<FORMULA>(r.x, g.x, b.x) + luminance<FORMULA>(r.y, g.y, b.y)) +
+                   (luminance<FORMULA>(r.z, g.z, b.z) + luminance<FORMULA>(r.w, g.w, b.w));
+            if (++run == 16) { part += (double)acc; acc = 0.0f; run = 0; }
+        }
+        part += (double)acc;
+    } else {
+        for (size_t i = tid; i < P; i += nthreads)
+            part += (double)luminance<FORMULA>(pr[i], pg[i], pb[i]);
+    }
+    part = wave_sum(part);
+    __shared__ double wave_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_part[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(sum, (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]));
+}
+
+__global__ __launch_bounds__(256) void refresh_std_dev_kernel(float* __restrict__ planes, size_t P,
+                                                              float n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    for (int k = 0; k < 5; k++) {
+        float v0 = planes[(size_t)(PTK_PL_SDV + 3 * k + 0) * P + i];
+        float v1 = planes[(size_t)(PTK_PL_SDV + 3 * k + 1) * P + i];
+        float v2 = planes[(size_t)(PTK_PL_SDV + 3 * k + 2) * P + i];
+        planes[(size_t)(PTK_PL_SD + k) * P + i] = (v0 + v1 + v2) / n;
+    }
+    planes[(size_t)(PTK_PL_SD + 5) * P + i] = planes[(size_t)(PTK_PL_SDV + 15) * P + i] / n;
+}
+
+}  // namespace
+
+hipError_t ptk_launch_exposure(const float* planes, size_t pixels, int formula, double* sum_d,
+                               hipStream_t stream)
+{
+    size_t work = (pixels & 3) == 0 ? pixels / 4 : pixels;
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (formula == 1)
+        hipLaunchKernelGGL(exposure_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, planes,
+                           pixels, sum_d);
+    else
+        hipLaunchKernelGGL(exposure_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, planes,
+                           pixels, sum_d);
+    return hipGetLastError();
+}
+
+hipError_t ptk_launch_refresh_std_dev(float* planes, size_t pixels, int sample_count,
+                                      hipStream_t stream)
+{
+    unsigned blocks = (unsigned)((pixels + 255) / 256);
+    hipLaunchKernelGGL(refresh_std_dev_kernel, dim3(blocks), dim3(256), 0, stream, planes, pixels,
+                       (float)sample_count);
+    return hipGetLastError();
+}

@@ -1,0 +1,630 @@
+// ptk_api.cpp -- host side of libptk: context, HBM buffers, scene compilation,
+// seed generation, launches.  Everything here runs on the caller's thread;
+// device work is enqueued on one stream per context.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "ptk_dev.h"
+
+static_assert(sizeof(ptk_constants) == PTK_CONSTANTS_BYTES, "ptk_constants must match the reference POD");
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(PTK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+// Seed passes are uploaded in chunks of at most this many bytes.
+constexpr size_t SEED_CHUNK_BYTES = size_t(256) << 20;
+
+}  // namespace
+
+struct ptk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+
+    bool have_scene = false;
+    DevScene host_scene;
+    DevScene* scene_d = nullptr;
+    int width = 0, height = 0;
+    size_t pixels = 0;
+    int max_depth = 4;
+    bool features = false;
+    int math_mode = PTK_MATH_EXACT;
+    uint64_t stream_id = 0;
+    int sample_count = 0;
+
+    float* planes_d = nullptr;        // PTK_N_PLANES * pixels
+    int64_t* seeds_d = nullptr;       // seed chunk
+    int64_t* seeds_h = nullptr;       // pinned staging for the chunk
+    size_t seed_capacity = 0;         // in passes
+    unsigned long long* rays_d = nullptr;
+    double* sum_d = nullptr;
+
+    float* weights_d = nullptr;       // 530 floats
+    float* variances_d = nullptr;     // 7 planes
+    float* features_d = nullptr;      // 36 planes (allocated on demand)
+    float* denoised_d = nullptr;      // 3 planes
+    float* wcsum_d = nullptr;         // 1 plane
+    float* staging_h = nullptr;       // pinned, for layout conversion on read-back
+    size_t staging_floats = 0;
+
+    ptk_times times;
+};
+
+namespace {
+
+int bind(ptk_ctx* c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return PTK_OK;
+}
+
+void free_image_buffers(ptk_ctx* c)
+{
+    hipFree(c->planes_d); c->planes_d = nullptr;
+    hipFree(c->seeds_d); c->seeds_d = nullptr;
+    if (c->seeds_h) hipHostFree(c->seeds_h);
+    c->seeds_h = nullptr;
+    c->seed_capacity = 0;
+    hipFree(c->variances_d); c->variances_d = nullptr;
+    hipFree(c->features_d); c->features_d = nullptr;
+    hipFree(c->denoised_d); c->denoised_d = nullptr;
+    hipFree(c->wcsum_d); c->wcsum_d = nullptr;
+    if (c->staging_h) hipHostFree(c->staging_h);
+    c->staging_h = nullptr;
+    c->staging_floats = 0;
+}
+
+int ensure_staging(ptk_ctx* c, size_t floats)
+{
+    if (c->staging_floats >= floats) return PTK_OK;
+    if (c->staging_h) hipHostFree(c->staging_h);
+    c->staging_h = nullptr;
+    c->staging_floats = 0;
+    HIP_TRY(hipHostMalloc((void**)&c->staging_h, floats * sizeof(float), hipHostMallocDefault));
+    c->staging_floats = floats;
+    return PTK_OK;
+}
+
+// Scene POD -> device layout.  Derived values are computed here in fp32 with
+// the reference's operation order so the kernel reads what it would have
+// computed itself (this translation unit is built without FMA contraction).
+int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
+{
+    if (k.res_h <= 0 || k.res_v <= 0 || (int64_t)k.res_h * k.res_v > (int64_t)1 << 28)
+        return fail(PTK_ERR_ARG, "resolution %dx%d out of range", k.res_h, k.res_v);
+    if (k.num_shapes < 0 || k.num_shapes > PTK_MAX_SHAPES)
+        return fail(PTK_ERR_ARG, "num_shapes %d outside [0,%d]", k.num_shapes, PTK_MAX_SHAPES);
+    if (k.max_depth < 1 || k.max_depth > PTK_MAX_DEPTH)
+        return fail(PTK_ERR_ARG, "max_depth %d outside [1,%d]", k.max_depth, PTK_MAX_DEPTH);
+    if (k.num_important_shapes > PTK_MAX_IMPORTANT)
+        return fail(PTK_ERR_ARG, "num_important_shapes %u > %d", k.num_important_shapes,
+                    PTK_MAX_IMPORTANT);
+
+    std::memset(&d, 0, sizeof d);
+    for (int i = 0; i < 3; i++) {
+        d.cam_pos[i] = k.cam_pos[i];
+        d.cam_fwd[i] = k.cam_forward[i];
+        d.cam_right[i] = k.cam_right[i];
+        d.cam_up[i] = k.cam_up[i];
+    }
+    d.rand_samp = k.rand_samp;
+    d.max_angle_v = k.max_angle_v;
+    d.max_angle_h = k.max_angle_h;
+    d.focal = k.focal_length;
+    d.num_shapes = k.num_shapes;
+    d.max_depth = k.max_depth;
+    d.res_v = k.res_v;
+    d.res_h = k.res_h;
+    d.num_imp = (int)k.num_important_shapes;
+    d.want_features = want_features;
+    d.inv_depth = 1.0f / (float)k.max_depth;
+    d.imp_boost = k.num_important_shapes > 1 ? (float)k.num_important_shapes : 1.0f;
+    for (uint32_t i = 0; i < k.num_important_shapes; i++) {
+        if (k.important_shapes[i] >= (uint32_t)k.num_shapes)
+            return fail(PTK_ERR_ARG, "important shape %u = %u is not a shape index", i,
+                        k.important_shapes[i]);
+        d.imp[i] = (int)k.important_shapes[i];
+    }
+    std::memcpy(d.mats, k.mat_list, sizeof d.mats);
+
+    const float E = 0.00001f;
+    for (int s = 0; s < k.num_shapes; s++) {
+        int type = k.shapes[s][0], mat = k.shapes[s][1], a = k.shapes[s][2];
+        if (type != 0 && type != 1) return fail(PTK_ERR_ARG, "shape %d has type %d", s, type);
+        if (mat < 0 || mat >= PTK_MAX_MATS)
+            return fail(PTK_ERR_ARG, "shape %d has material %d", s, mat);
+        int need = type == 0 ? 4 : 13;
+        if (a < 0 || a + need > PTK_MAX_ATTRS)
+            return fail(PTK_ERR_ARG, "shape %d attribute range [%d,%d) exceeds %d", s, a, a + need,
+                        PTK_MAX_ATTRS);
+        const float* at = k.obj_attributes + a;
+        DevShape& o = d.shape[s];
+        o.type = type;
+        o.mat = mat;
+        o.mat_type = (int)k.mat_list[mat][5];
+        o.flat_axis = -1;
+        o.c[0] = at[0]; o.c[1] = at[1]; o.c[2] = at[2];
+        if (type == 0) {
+            o.r = at[3];
+            o.rsq = at[3] * at[3];
+            o.q[0] = 1.0f;
+        } else {
+            for (int i = 0; i < 3; i++) { o.lo[i] = at[3 + i]; o.hi[i] = at[6 + i]; }
+            for (int i = 0; i < 4; i++) o.q[i] = at[9 + i];
+            o.rotated = (at[10] + at[11] + at[12] > E) ? 1 : 0;
+            for (int i = 2; i >= 0; i--)
+                if (std::fabs(o.lo[i] - o.hi[i]) < E) o.flat_axis = i;
+            // importance pdf area (Renderers.cpp:691-697)
+            float dx = at[3] - at[6], dy = at[4] - at[7], dz = at[5] - at[8];
+            float area = 0;
+            area += dx * dy * 2.0f;
+            area += dz * dy * 2.0f;
+            area += dx * dz * 2.0f;
+            o.area = area;
+        }
+    }
+    return PTK_OK;
+}
+
+// The reference's global seed step (Renderers.cpp:832-838).
+inline void seed_step(uint64_t& g0, uint64_t& g1)
+{
+    uint64_t a = g0, b = g1;
+    b ^= a;
+    g0 = (a << 49) | ((a >> 15) ^ b ^ (b << 21));
+    g1 = (b << 28) | (b >> 36);
+}
+
+double elapsed_ms(ptk_ctx* c)
+{
+    float ms = 0.0f;
+    if (hipEventSynchronize(c->ev[1]) != hipSuccess) return 0.0;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) != hipSuccess) return 0.0;
+    return (double)ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptk_last_error(void) { return g_err; }
+
+int ptk_create(int device, ptk_ctx** out)
+{
+    if (!out) return fail(PTK_ERR_ARG, "ptk_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return fail(PTK_ERR_ARG, "ptk_create: device %d of %d", device, count);
+    ptk_ctx* c = new (std::nothrow) ptk_ctx();
+    if (!c) return fail(PTK_ERR_NOMEM, "ptk_create: out of host memory");
+    c->device = device;
+    std::memset(&c->times, 0, sizeof c->times);
+    int rc = bind(c);
+    if (rc != PTK_OK) { delete c; return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev[0]);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev[1]);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->scene_d, sizeof(DevScene));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->rays_d, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->sum_d, sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->weights_d, 530 * sizeof(float));
+    if (e != hipSuccess) {
+        ptk_destroy(c);
+        return fail(PTK_ERR_HIP, "ptk_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PTK_OK;
+}
+
+int ptk_destroy(ptk_ctx* c)
+{
+    if (!c) return PTK_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_image_buffers(c);
+    hipFree(c->scene_d);
+    hipFree(c->rays_d);
+    hipFree(c->sum_d);
+    hipFree(c->weights_d);
+    if (c->ev[0]) hipEventDestroy(c->ev[0]);
+    if (c->ev[1]) hipEventDestroy(c->ev[1]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return PTK_OK;
+}
+
+int ptk_set_constants(ptk_ctx* c, const void* constants, size_t nbytes, int want_denoise_features)
+{
+    if (!c || !constants) return fail(PTK_ERR_ARG, "ptk_set_constants: null argument");
+    if (nbytes != PTK_CONSTANTS_BYTES)
+        return fail(PTK_ERR_ARG, "ptk_set_constants: expected %d bytes, got %zu",
+                    PTK_CONSTANTS_BYTES, nbytes);
+    ptk_constants k;
+    std::memcpy(&k, constants, sizeof k);
+    int feats = want_denoise_features >= 0 ? (want_denoise_features ? 1 : 0)
+                                           : (k.get_denoiser_inf == 1 ? 1 : 0);
+    DevScene d;
+    int rc = compile_scene(k, feats, d);
+    if (rc != PTK_OK) return rc;
+    if ((rc = bind(c)) != PTK_OK) return rc;
+
+    if (k.res_h != c->width || k.res_v != c->height || !c->planes_d) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        free_image_buffers(c);
+        c->width = k.res_h;
+        c->height = k.res_v;
+        c->pixels = (size_t)k.res_h * (size_t)k.res_v;
+        const size_t P = c->pixels;
+        HIP_TRY(hipMalloc((void**)&c->planes_d, PTK_N_PLANES * P * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&c->variances_d, 7 * P * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&c->denoised_d, 3 * P * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&c->wcsum_d, P * sizeof(float)));
+    }
+    c->host_scene = d;
+    c->max_depth = k.max_depth;
+    c->features = feats != 0;
+    HIP_TRY(hipMemcpyAsync(c->scene_d, &c->host_scene, sizeof(DevScene), hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_scene = true;
+    return ptk_reset_accumulators(c);
+}
+
+int ptk_reset_accumulators(ptk_ctx* c)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_reset_accumulators: null context");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_reset_accumulators before ptk_set_constants");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->planes_d, 0, PTK_N_PLANES * c->pixels * sizeof(float), c->stream));
+    c->sample_count = 0;
+    return PTK_OK;
+}
+
+int ptk_set_math_mode(ptk_ctx* c, int mode)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_set_math_mode: null context");
+    if (mode != PTK_MATH_EXACT && mode != PTK_MATH_FAST)
+        return fail(PTK_ERR_ARG, "ptk_set_math_mode: unknown mode %d", mode);
+    c->math_mode = mode;
+    return PTK_OK;
+}
+
+int ptk_set_stream_id(ptk_ctx* c, uint64_t stream_id)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_set_stream_id: null context");
+    c->stream_id = stream_id;
+    return PTK_OK;
+}
+
+int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_t* rays_out)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_render: null context");
+    if (!c->have_scene) return fail(PTK_ERR_STATE, "ptk_render before ptk_set_constants");
+    if (spp < 0) return fail(PTK_ERR_ARG, "ptk_render: spp %d < 0", spp);
+    if (seed_mode != PTK_SEED_REFERENCE && seed_mode != PTK_SEED_COUNTER)
+        return fail(PTK_ERR_ARG, "ptk_render: unknown seed mode %d", seed_mode);
+    if (seed_mode == PTK_SEED_REFERENCE && !glo_seed)
+        return fail(PTK_ERR_ARG, "ptk_render: reference seed mode needs glo_seed");
+    if ((int64_t)c->sample_count + spp > 0x7fffffff)
+        return fail(PTK_ERR_ARG, "ptk_render: sample count would overflow");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+
+    const size_t P = c->pixels;
+    HIP_TRY(hipMemsetAsync(c->rays_d, 0, sizeof(unsigned long long), c->stream));
+    RenderArgs a;
+    a.scene = c->scene_d;
+    a.planes = c->planes_d;
+    a.rays = c->rays_d;
+    a.stream_id = c->stream_id;
+    a.width = c->width;
+    a.height = c->height;
+    auto launch = c->math_mode == PTK_MATH_FAST ? ptk_launch_render_fast : ptk_launch_render_exact;
+
+    double render_ms = 0.0, seed_ms = 0.0;
+    if (seed_mode == PTK_SEED_COUNTER) {
+        a.seeds = nullptr;
+        a.spp = spp;
+        a.base_count = c->sample_count;
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        if (spp > 0) HIP_TRY(launch(a, c->max_depth, c->features, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        render_ms = elapsed_ms(c);
+        c->sample_count += spp;
+    } else {
+        size_t per_pass = P * 2 * sizeof(int64_t);
+        size_t want = SEED_CHUNK_BYTES / per_pass;
+        if (want < 1) want = 1;
+        if (want > (size_t)spp) want = (size_t)spp;
+        if (want > c->seed_capacity) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(c->seeds_d); c->seeds_d = nullptr;
+            if (c->seeds_h) hipHostFree(c->seeds_h);
+            c->seeds_h = nullptr;
+            c->seed_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&c->seeds_d, want * per_pass));
+            HIP_TRY(hipHostMalloc((void**)&c->seeds_h, want * per_pass, hipHostMallocDefault));
+            c->seed_capacity = want;
+        }
+        uint64_t g0 = glo_seed[0], g1 = glo_seed[1];
+        int done = 0;
+        while (done < spp) {
+            int chunk = spp - done;
+            if ((size_t)chunk > c->seed_capacity) chunk = (int)c->seed_capacity;
+            timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            int64_t* h = c->seeds_h;
+            const size_t n = (size_t)chunk * P;
+            for (size_t i = 0; i < n; i++) {
+                seed_step(g0, g1);
+                h[2 * i] = (int64_t)g0;
+                h[2 * i + 1] = (int64_t)g1;
+            }
+            HIP_TRY(hipMemcpyAsync(c->seeds_d, h, n * 2 * sizeof(int64_t), hipMemcpyHostToDevice,
+                                   c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            seed_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+            a.seeds = c->seeds_d;
+            a.spp = chunk;
+            a.base_count = c->sample_count;
+            HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+            HIP_TRY(launch(a, c->max_depth, c->features, c->stream));
+            HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+            render_ms += elapsed_ms(c);
+            c->sample_count += chunk;
+            done += chunk;
+        }
+        glo_seed[0] = g0;
+        glo_seed[1] = g1;
+    }
+    unsigned long long rays = 0;
+    HIP_TRY(hipMemcpyAsync(&rays, c->rays_d, sizeof rays, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (rays_out) *rays_out = rays;
+    c->times.render_ms = render_ms;
+    c->times.seed_ms = seed_ms;
+    c->times.render_samples = (uint64_t)P * (uint64_t)spp;
+    c->times.render_rays = rays;
+    return PTK_OK;
+}
+
+int ptk_read_planes(ptk_ctx* c, int first_plane, int n_planes, float* out)
+{
+    if (!c || !out) return fail(PTK_ERR_ARG, "ptk_read_planes: null argument");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_read_planes before ptk_set_constants");
+    if (first_plane < 0 || n_planes < 0 || first_plane + n_planes > PTK_N_PLANES)
+        return fail(PTK_ERR_ARG, "ptk_read_planes: planes [%d,%d) outside [0,%d)", first_plane,
+                    first_plane + n_planes, PTK_N_PLANES);
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->planes_d + (size_t)first_plane * c->pixels,
+                           (size_t)n_planes * c->pixels * sizeof(float), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_write_planes(ptk_ctx* c, int first_plane, int n_planes, const float* in, int sample_count)
+{
+    if (!c || !in) return fail(PTK_ERR_ARG, "ptk_write_planes: null argument");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_write_planes before ptk_set_constants");
+    if (first_plane < 0 || n_planes < 0 || first_plane + n_planes > PTK_N_PLANES)
+        return fail(PTK_ERR_ARG, "ptk_write_planes: planes [%d,%d) outside [0,%d)", first_plane,
+                    first_plane + n_planes, PTK_N_PLANES);
+    if (sample_count < 0) return fail(PTK_ERR_ARG, "ptk_write_planes: sample_count %d", sample_count);
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->planes_d + (size_t)first_plane * c->pixels, in,
+                           (size_t)n_planes * c->pixels * sizeof(float), hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sample_count = sample_count;
+    return PTK_OK;
+}
+
+int ptk_read_accumulators(ptk_ctx* c, float* pre_screen, float* normal, float* albedo1,
+                          float* albedo2, float* direct_light, float* world_pos, float* std_dev,
+                          int* sample_count)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_read_accumulators: null context");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_read_accumulators before ptk_set_constants");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    const size_t P = c->pixels;
+    if ((rc = ensure_staging(c, 6 * P)) != PTK_OK) return rc;
+    struct { float* dst; int plane; int n; } jobs[] = {
+        {pre_screen, PTK_PL_COL, 3}, {normal, PTK_PL_NORMAL, 3}, {albedo1, PTK_PL_ALB1, 3},
+        {albedo2, PTK_PL_ALB2, 3},   {direct_light, PTK_PL_DL, 1}, {world_pos, PTK_PL_WPOS, 3},
+        {std_dev, PTK_PL_SD, 6},
+    };
+    for (auto& j : jobs) {
+        if (!j.dst) continue;
+        HIP_TRY(hipMemcpyAsync(c->staging_h, c->planes_d + (size_t)j.plane * P,
+                               (size_t)j.n * P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < P; i++)
+            for (int k = 0; k < j.n; k++) j.dst[i * j.n + k] = c->staging_h[(size_t)k * P + i];
+    }
+    if (sample_count) *sample_count = c->sample_count;
+    return PTK_OK;
+}
+
+int ptk_planes_device(ptk_ctx* c, float** base_d, size_t* pixels_per_plane)
+{
+    if (!c || !base_d || !pixels_per_plane)
+        return fail(PTK_ERR_ARG, "ptk_planes_device: null argument");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_planes_device before ptk_set_constants");
+    *base_d = c->planes_d;
+    *pixels_per_plane = c->pixels;
+    return PTK_OK;
+}
+
+int ptk_get_sample_count(ptk_ctx* c, int* sample_count)
+{
+    if (!c || !sample_count) return fail(PTK_ERR_ARG, "ptk_get_sample_count: null argument");
+    *sample_count = c->sample_count;
+    return PTK_OK;
+}
+
+int ptk_set_sample_count(ptk_ctx* c, int sample_count)
+{
+    if (!c || sample_count < 0) return fail(PTK_ERR_ARG, "ptk_set_sample_count: bad argument");
+    c->sample_count = sample_count;
+    return PTK_OK;
+}
+
+int ptk_refresh_std_dev(ptk_ctx* c)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_refresh_std_dev: null context");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_refresh_std_dev before ptk_set_constants");
+    if (c->sample_count < 1) return fail(PTK_ERR_STATE, "ptk_refresh_std_dev: no samples");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(ptk_launch_refresh_std_dev(c->planes_d, c->pixels, c->sample_count, c->stream));
+    return PTK_OK;
+}
+
+int ptk_auto_exposure(ptk_ctx* c, int formula, float* exposure, double* raw_sum)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_auto_exposure: null context");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_auto_exposure before ptk_set_constants");
+    if (formula < 0 || formula > 2) return fail(PTK_ERR_ARG, "ptk_auto_exposure: formula %d", formula);
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->sum_d, 0, sizeof(double), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(ptk_launch_exposure(c->planes_d, c->pixels, formula == 1 ? 1 : 0, c->sum_d, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    double sum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sum, c->sum_d, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->times.exposure_ms = elapsed_ms(c);
+    if (raw_sum) *raw_sum = sum;
+    if (exposure) {
+        const float n = (float)c->sample_count;
+        float e = (float)sum;
+        if (formula == PTK_EXPOSURE_CPU)
+            e *= 9.6f / (float)c->width * (float)c->height * n;  // as written, left to right
+        else if (formula == PTK_EXPOSURE_SKEPU)
+            e = 9.6f * e / (float)(int)c->pixels * n;
+        else
+            e = (float)(9.6 * sum / ((double)c->pixels * (double)c->sample_count));
+        *exposure = e;
+    }
+    return PTK_OK;
+}
+
+int ptk_denoise(ptk_ctx* c, const float* w12, const float* w23, const float* w34, int n,
+                int variant, float* denoised, float* wc_sum, float* variances, float* features)
+{
+    if (!c || !w12 || !w23 || !w34) return fail(PTK_ERR_ARG, "ptk_denoise: null argument");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_denoise before ptk_set_constants");
+    if (c->sample_count < 1) return fail(PTK_ERR_STATE, "ptk_denoise: no samples accumulated");
+    if (n < 0 || n > 8) return fail(PTK_ERR_ARG, "ptk_denoise: N %d outside [0,8]", n);
+    if (variant != 0 && variant != 1) return fail(PTK_ERR_ARG, "ptk_denoise: variant %d", variant);
+    if (variant == 1 && features)
+        return fail(PTK_ERR_ARG, "ptk_denoise: the fused variant does not materialise features");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    const size_t P = c->pixels;
+    float w[530];
+    std::memcpy(w, w12, 360 * sizeof(float));
+    std::memcpy(w + 360, w23, 100 * sizeof(float));
+    std::memcpy(w + 460, w34, 70 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(c->weights_d, w, sizeof w, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // w is on this frame's stack
+    if (features && !c->features_d) HIP_TRY(hipMalloc((void**)&c->features_d, 36 * P * sizeof(float)));
+
+    DenoiseArgs a;
+    a.planes = c->planes_d;
+    a.weights = c->weights_d;
+    a.variances = c->variances_d;
+    a.features = features ? c->features_d : nullptr;
+    a.denoised = c->denoised_d;
+    a.wc_sum = c->wcsum_d;
+    a.width = c->width;
+    a.height = c->height;
+    a.sample_count = c->sample_count;
+    a.n = n;
+    if (variant == 0) {
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(ptk_launch_features_mlp(a, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        c->times.features_ms = elapsed_ms(c);
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(ptk_launch_filter(a, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        c->times.filter_ms = elapsed_ms(c);
+        c->times.denoise_ms = c->times.features_ms + c->times.filter_ms;
+    } else {
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(ptk_launch_denoise_fused(a, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        c->times.denoise_ms = elapsed_ms(c);
+        c->times.features_ms = 0.0;
+        c->times.filter_ms = 0.0;
+    }
+
+    struct { float* dst; const float* src; int n; } jobs[] = {
+        {denoised, c->denoised_d, 3}, {wc_sum, c->wcsum_d, 1},
+        {variances, c->variances_d, 7}, {features, c->features_d, 36},
+    };
+    for (auto& j : jobs) {
+        if (!j.dst) continue;
+        if ((rc = ensure_staging(c, (size_t)j.n * P)) != PTK_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->staging_h, j.src, (size_t)j.n * P * sizeof(float),
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < P; i++)
+            for (int k = 0; k < j.n; k++) j.dst[i * j.n + k] = c->staging_h[(size_t)k * P + i];
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_timing(ptk_ctx* c, ptk_times* out)
+{
+    if (!c || !out) return fail(PTK_ERR_ARG, "ptk_timing: null argument");
+    *out = c->times;
+    return PTK_OK;
+}
+
+int ptk_synchronize(ptk_ctx* c)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_synchronize: null context");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+}  // extern "C"

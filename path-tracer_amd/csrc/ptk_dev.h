@@ -1,0 +1,85 @@
+// ptk_dev.h -- device-side data layout and kernel launch entry points shared by
+// the host API (ptk_api.cpp) and the HIP kernels.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/ptk.h"
+
+// One shape of the compiled scene.  The closest-hit and shadow scans index
+// this array with the (wave-uniform) loop counter, so its fields arrive in
+// SGPRs through scalar loads; the copy in LDS serves per-lane lookups of the
+// shape a lane actually hit.  Stride is 25 dwords so per-lane LDS reads of
+// different shapes spread over the banks.
+struct DevShape {
+    float c[3];    // centre (sphere centre / box position)
+    float lo[3];   // box bounds, world space (unused for spheres)
+    float hi[3];
+    float q[4];    // box quaternion w,x,y,z
+    float r;       // sphere radius
+    float rsq;     // r*r, rounded once on the host exactly as the kernel would
+    float area;    // box: 2(xy+zy+xz) of the extents, reference operation order
+    int32_t type;      // 0 sphere, 1 box
+    int32_t mat;       // material index
+    int32_t mat_type;  // (int)mat_list[mat][5]
+    int32_t rotated;   // q.x + q.y + q.z > 1e-5f
+    int32_t flat_axis; // first axis with |lo-hi| < 1e-5f, or -1
+    int32_t pad[4];
+};
+static_assert(sizeof(DevShape) == 25 * 4, "DevShape must be 25 dwords");
+
+struct DevScene {
+    float cam_pos[3], cam_fwd[3], cam_right[3], cam_up[3];
+    float rand_samp, max_angle_v, max_angle_h, focal;
+    int32_t num_shapes, max_depth, res_v, res_h;
+    int32_t num_imp, want_features;
+    int32_t imp[PTK_MAX_IMPORTANT];
+    float inv_depth;   // 1.0f / (float)max_depth
+    float imp_boost;   // (float)num_imp when num_imp > 1, else 1
+    DevShape shape[PTK_MAX_SHAPES];
+    float mats[PTK_MAX_MATS][6];
+};
+
+struct RenderArgs {
+    const DevScene* scene;   // device memory
+    float* planes;           // PTK_N_PLANES * P floats
+    const int64_t* seeds;    // seed mode 0: [pass][pixel][2]; null in counter mode
+    unsigned long long* rays; // device counter, incremented by the call's bounce rays
+    uint64_t stream_id;      // counter mode
+    int32_t width, height;
+    int32_t spp;             // passes in this launch
+    int32_t base_count;      // sampleCount before this launch
+};
+
+// Launchers (defined next to their kernels).  All enqueue on `stream` and
+// return the launch status; none synchronises or allocates.
+hipError_t ptk_launch_render_exact(const RenderArgs& a, int max_depth, bool features,
+                                   hipStream_t stream);
+hipError_t ptk_launch_render_fast(const RenderArgs& a, int max_depth, bool features,
+                                  hipStream_t stream);
+
+// Luminance map + sum of planes 0..2 into *sum_d (must be zero on entry).
+hipError_t ptk_launch_exposure(const float* planes, size_t pixels, int formula, double* sum_d,
+                               hipStream_t stream);
+
+// stdDev[k] = (sdv[3k] + sdv[3k+1] + sdv[3k+2]) / n for k < 5, sdv[15] / n for k = 5.
+hipError_t ptk_launch_refresh_std_dev(float* planes, size_t pixels, int sample_count,
+                                      hipStream_t stream);
+
+struct DenoiseArgs {
+    const float* planes;
+    const float* weights;   // 530 floats: w12, w23, w34 (device)
+    float* variances;       // 7 planes, plane-major (device)
+    float* features;        // 36 planes, plane-major, or null
+    float* denoised;        // 3 planes, plane-major
+    float* wc_sum;          // 1 plane
+    int32_t width, height;
+    int32_t sample_count;
+    int32_t n;              // filter half-width
+};
+hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream);
+hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream);
+hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream);

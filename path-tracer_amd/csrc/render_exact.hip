@@ -1,0 +1,17 @@
+// render_exact.hip -- PTK_MATH_EXACT instantiation of the path-trace kernel:
+// IEEE divide/sqrt, no FMA contraction, reference operation order.
+#include <hip/hip_runtime.h>
+
+#include "ptk_dev.h"
+
+#define PTK_FAST 0
+#pragma clang fp contract(off)
+#include "render_kernel.inc"
+
+hipError_t ptk_launch_render_exact(const RenderArgs& a, int max_depth, bool features,
+                                   hipStream_t stream)
+{
+    if (max_depth <= 4) return launch_depth<4>(a, features, stream);
+    if (max_depth <= 8) return launch_depth<8>(a, features, stream);
+    return launch_depth<12>(a, features, stream);
+}

@@ -1,0 +1,19 @@
+// render_fast.hip -- PTK_MATH_FAST instantiation of the path-trace kernel:
+// reciprocal-based slab tests and normalisation, hardware sin/cos, FMA
+// contraction.  Same sampling decisions and estimator; values differ from
+// EXACT mode at the 1e-6 relative level per operation.
+#include <hip/hip_runtime.h>
+
+#include "ptk_dev.h"
+
+#define PTK_FAST 1
+#pragma clang fp contract(fast)
+#include "render_kernel.inc"
+
+hipError_t ptk_launch_render_fast(const RenderArgs& a, int max_depth, bool features,
+                                  hipStream_t stream)
+{
+    if (max_depth <= 4) return launch_depth<4>(a, features, stream);
+    if (max_depth <= 8) return launch_depth<8>(a, features, stream);
+    return launch_depth<12>(a, features, stream);
+}

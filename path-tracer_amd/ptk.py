@@ -1,0 +1,217 @@
+"""ctypes binding of libptk.so (the C ABI of include/ptk.h).
+
+This module only marshals arguments; every computation happens in the HIP
+library.  There is no CPU fallback: if libptk.so is missing or a call fails,
+an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptk.so")
+
+CONSTANTS_BYTES = 3732
+N_PLANES = 38
+PL_COL, PL_NORMAL, PL_ALB1, PL_ALB2, PL_WPOS, PL_DL, PL_SDV, PL_SD = 0, 3, 6, 9, 12, 15, 16, 32
+SEED_REFERENCE, SEED_COUNTER = 0, 1
+MATH_EXACT, MATH_FAST = 0, 1
+EXPOSURE_CPU, EXPOSURE_SKEPU, EXPOSURE_MEAN = 0, 1, 2
+
+EXPORTS = [
+    "ptk_create", "ptk_destroy", "ptk_last_error", "ptk_set_constants", "ptk_reset_accumulators",
+    "ptk_set_math_mode", "ptk_set_stream_id", "ptk_render", "ptk_read_accumulators",
+    "ptk_read_planes", "ptk_write_planes", "ptk_planes_device", "ptk_get_sample_count",
+    "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
+    "ptk_timing", "ptk_synchronize",
+]
+
+
+class PtkError(RuntimeError):
+    pass
+
+
+class Times(C.Structure):
+    _fields_ = [("render_ms", C.c_double), ("seed_ms", C.c_double), ("exposure_ms", C.c_double),
+                ("features_ms", C.c_double), ("filter_ms", C.c_double), ("denoise_ms", C.c_double),
+                ("render_samples", C.c_uint64), ("render_rays", C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libptk.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtkError("libptk.so not found at %s: build it with `make -C path-tracer_amd` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    vp = C.c_void_p
+    L.ptk_last_error.restype = C.c_char_p
+    L.ptk_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ptk_destroy.argtypes = [vp]
+    L.ptk_set_constants.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.ptk_reset_accumulators.argtypes = [vp]
+    L.ptk_set_math_mode.argtypes = [vp, C.c_int]
+    L.ptk_set_stream_id.argtypes = [vp, C.c_uint64]
+    L.ptk_render.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ptk_read_accumulators.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, C.POINTER(C.c_int)]
+    L.ptk_read_planes.argtypes = [vp, C.c_int, C.c_int, fp]
+    L.ptk_write_planes.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int]
+    L.ptk_planes_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ptk_get_sample_count.argtypes = [vp, C.POINTER(C.c_int)]
+    L.ptk_set_sample_count.argtypes = [vp, C.c_int]
+    L.ptk_refresh_std_dev.argtypes = [vp]
+    L.ptk_auto_exposure.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_double)]
+    L.ptk_denoise.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]
+    L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
+    L.ptk_synchronize.argtypes = [vp]
+    for name in EXPORTS:
+        if name != "ptk_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _fp(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Context:
+    """One GPU's renderer/denoiser state (wraps ptk_ctx)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._check(self._L.ptk_create(device, C.byref(self._h)))
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PtkError("libptk error %d: %s" % (rc, self._L.ptk_last_error().decode()))
+
+    def close(self):
+        if self._h:
+            self._L.ptk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_constants(self, constants, want_features=-1):
+        """constants: any object exposing the 3732-byte scene POD through the buffer protocol."""
+        raw = bytes(constants)
+        buf = C.create_string_buffer(raw, len(raw))
+        self._check(self._L.ptk_set_constants(self._h, C.cast(buf, C.c_void_p), len(raw),
+                                              want_features))
+        hdr = np.frombuffer(raw, dtype=np.int32, count=20)
+        self.height, self.width = int(hdr[16]), int(hdr[17])
+
+    @property
+    def pixels(self):
+        return self.width * self.height
+
+    def reset(self):
+        self._check(self._L.ptk_reset_accumulators(self._h))
+
+    def set_math_mode(self, mode):
+        self._check(self._L.ptk_set_math_mode(self._h, mode))
+
+    def set_stream_id(self, sid):
+        self._check(self._L.ptk_set_stream_id(self._h, sid))
+
+    def render(self, spp, seed_mode=SEED_COUNTER, glo=None):
+        """Returns (rays, glo_after)."""
+        rays = C.c_uint64(0)
+        if seed_mode == SEED_REFERENCE:
+            st = (C.c_uint64 * 2)(glo[0], glo[1])
+            self._check(self._L.ptk_render(self._h, spp, seed_mode, st, C.byref(rays)))
+            return int(rays.value), (int(st[0]), int(st[1]))
+        self._check(self._L.ptk_render(self._h, spp, seed_mode, None, C.byref(rays)))
+        return int(rays.value), glo
+
+    def read_planes(self, first=0, count=N_PLANES):
+        out = np.empty((count, self.pixels), dtype=np.float32)
+        self._check(self._L.ptk_read_planes(self._h, first, count, _fp(out)))
+        return out
+
+    def write_planes(self, planes, sample_count, first=0):
+        planes = np.ascontiguousarray(planes, dtype=np.float32)
+        self._check(self._L.ptk_write_planes(self._h, first, planes.shape[0], _fp(planes),
+                                             sample_count))
+
+    def read_accumulators(self):
+        """The accumulators in the layout of the reference's globals."""
+        P = self.pixels
+        out = {k: np.empty((P, 3), np.float32) for k in
+               ("preScreen", "normal", "albedo1", "albedo2", "worldPos")}
+        out["directLight"] = np.empty(P, np.float32)
+        out["stdDev"] = np.empty((P, 6), np.float32)
+        sc = C.c_int(0)
+        self._check(self._L.ptk_read_accumulators(
+            self._h, _fp(out["preScreen"]), _fp(out["normal"]), _fp(out["albedo1"]),
+            _fp(out["albedo2"]), _fp(out["directLight"]), _fp(out["worldPos"]),
+            _fp(out["stdDev"]), C.byref(sc)))
+        out["sampleCount"] = sc.value
+        return out
+
+    def planes_device(self):
+        base = C.c_void_p()
+        n = C.c_size_t(0)
+        self._check(self._L.ptk_planes_device(self._h, C.byref(base), C.byref(n)))
+        return int(base.value), int(n.value)
+
+    @property
+    def sample_count(self):
+        sc = C.c_int(0)
+        self._check(self._L.ptk_get_sample_count(self._h, C.byref(sc)))
+        return sc.value
+
+    @sample_count.setter
+    def sample_count(self, v):
+        self._check(self._L.ptk_set_sample_count(self._h, int(v)))
+
+    def refresh_std_dev(self):
+        self._check(self._L.ptk_refresh_std_dev(self._h))
+
+    def auto_exposure(self, formula=EXPOSURE_CPU):
+        e = C.c_float(0)
+        raw = C.c_double(0)
+        self._check(self._L.ptk_auto_exposure(self._h, formula, C.byref(e), C.byref(raw)))
+        return float(e.value), float(raw.value)
+
+    def denoise(self, weights, n=1, variant=0, want_outputs=True, want_features=False):
+        """Returns dict(denoised (P,3), wcSum (P,), variances (P,7), features (P,36)|None)."""
+        w12, w23, w34 = (np.ascontiguousarray(w, dtype=np.float32) for w in weights)
+        assert w12.size == 360 and w23.size == 100 and w34.size == 70
+        P = self.pixels
+        res = {"denoised": None, "wcSum": None, "variances": None, "features": None}
+        if want_outputs:
+            res["denoised"] = np.empty((P, 3), np.float32)
+            res["wcSum"] = np.empty(P, np.float32)
+            res["variances"] = np.empty((P, 7), np.float32)
+        if want_features:
+            res["features"] = np.empty((P, 36), np.float32)
+        self._check(self._L.ptk_denoise(self._h, _fp(w12), _fp(w23), _fp(w34), n, variant,
+                                        _fp(res["denoised"]), _fp(res["wcSum"]),
+                                        _fp(res["variances"]), _fp(res["features"])))
+        return res
+
+    def timing(self):
+        t = Times()
+        self._check(self._L.ptk_timing(self._h, C.byref(t)))
+        return t
+
+    def synchronize(self):
+        self._check(self._L.ptk_synchronize(self._h))
