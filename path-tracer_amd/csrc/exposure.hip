@@ -3,8 +3,8 @@
 // a cross-GPU reduction.
 //
 // HBM-bound: 12 bytes read per pixel, one double atomic per workgroup.  Each
-// lane sums float4 slices in fp32 (the per-pixel term is the reference's fp32
-// expression), widens to double, and the wave reduces with DPP row operations.
+// lane reads float4 slices, evaluates the reference's fp32 per-pixel term and
+// sums in double; the wave reduces with DPP row operations.
 #include <hip/hip_runtime.h>
 
 #include "ptk_dev.h"
@@ -60,15 +60,14 @@ __global__ __launch_bounds__(256) void exposure_kernel(const float* __restrict__
         const float4* r4 = (const float4*)pr;
         const float4* g4 = (const float4*)pg;
         const float4* b4 = (const float4*)pb;
-        float acc = 0.0f;
-        int run = 0;
         for (size_t i = tid; i < n4; i += nthreads) {
             float4 r = r4[i], g = g4[i], b = b4[i];
-            acc += (luminance<FORMULA>(r.x, g.x, b.x) + luminance<FORMULA>(r.y, g.y, b.y)) +
-                   (luminance<FORMULA>(r.z, g.z, b.z) + luminance<FORMULA>(r.w, g.w, b.w));
-            if (++run == 16) { part += (double)acc; acc = 0.0f; run = 0; }
+            // every per-pixel term is the reference's fp32 value; the sum is double
+            part += ((double)luminance<FORMULA>(r.x, g.x, b.x) +
+                     (double)luminance<FORMULA>(r.y, g.y, b.y)) +
+                    ((double)luminance<FORMULA>(r.z, g.z, b.z) +
+                     (double)luminance<FORMULA>(r.w, g.w, b.w));
         }
-        part += (double)acc;
     } else {
         for (size_t i = tid; i < P; i += nthreads)
             part += (double)luminance<FORMULA>(pr[i], pg[i], pb[i]);

@@ -1,0 +1,264 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden fixtures.
+
+Tolerances (PTK_MATH_EXACT, matched reference seeds).  The kernel performs the
+reference's fp32 operations in the reference's order with IEEE divide/sqrt and
+no FMA contraction; the only places it cannot be bit-identical to the oracle
+are cosf/sinf/acosf/powf, where glibc is faithfully (not correctly) rounded.
+A one-ulp difference there perturbs a path's colour by ~1e-7 relative, and on
+rare paths flips a discrete decision (closest shape, refract/reflect, shadow
+test), after which that sample is a different, equally valid path.  Hence:
+
+  * RNG streams, ray counts, seed state: bit-exact.
+  * 1 spp: >= 99 % of pixels bit-identical in colour, >= 99.9 % within 1e-4
+    relative; first-hit feature planes identical on >= 99.9 % of pixels.
+  * 8 spp accumulators: >= 99.5 % of pixels within 1e-4 relative; image mean
+    within 1e-4 relative (the libm-variant noise floor of the reference itself
+    is 6e-5).
+  * exposure: raw sum within 1e-9 relative of the oracle's double sum, scaled
+    value within 2e-6 relative of the oracle's sequential-fp32 value at these
+    sizes.
+  * denoiser: discrete feature planes bit-exact; smooth planes, bandwidths,
+    filtered colour and weight sum within 2e-5 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PIN_SEED, scene_path, weights_path
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["cornell", "cornell_crystal", "MultiLightGlass", "Box_Grid", "blur_test", "bars3"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ptk
+    c = ptk.Context(0)
+    yield c
+    c.close()
+
+
+def _same(a, b):
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+def _rel_ok(a, b, rel, abs_=1e-7):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return _same(a, b) | (np.abs(a - b) <= rel * np.abs(b) + abs_)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_one_sample_per_pixel_matches_golden(ctx, name):
+    import ptk
+    g = np.load(os.path.join(GOLDEN, "render_%s_64x36.npz" % name))
+    ctx.set_math_mode(ptk.MATH_EXACT)
+    ctx.set_constants(g["constants"].tobytes())
+    rays, glo = ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    planes = ctx.read_planes()
+    ref = g["samples_1spp"]            # (P, 17): xyz, normal, alb1, alb2, wpos, dl, rays
+    assert rays == int(ref[:, 16].sum())
+    col_same = _same(planes[0:3].T, ref[:, 0:3]).all(axis=1)
+    assert col_same.mean() >= 0.99
+    assert _rel_ok(planes[0:3].T, ref[:, 0:3], 1e-4).all(axis=1).mean() >= 0.999
+    feat_same = _same(planes[3:16].T, ref[:, 3:16]).all(axis=1)
+    assert feat_same.mean() >= 0.999
+    # running statistics after one sample: deviation of the sample from itself
+    assert np.all(planes[32:38][:, col_same] == 0.0)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_eight_samples_match_golden_accumulators(ctx, name, oracle):
+    import ptk
+    g = np.load(os.path.join(GOLDEN, "render_%s_64x36.npz" % name))
+    ctx.set_math_mode(ptk.MATH_EXACT)
+    ctx.set_constants(g["constants"].tobytes())
+    # two calls (3 + 5) must equal one call of 8: the statistics carry over
+    _, glo = ctx.render(3, ptk.SEED_REFERENCE, PIN_SEED)
+    _, glo = ctx.render(5, ptk.SEED_REFERENCE, glo)
+    assert glo == tuple(int(x) for x in g["glo_after"])
+    assert ctx.sample_count == 8
+    planes = ctx.read_planes()
+    ref = g["acc_8spp"]
+    ok = _rel_ok(planes, ref, 1e-4).all(axis=0)
+    assert ok.mean() >= 0.995
+    m_gpu = np.nanmean(planes[0:3].astype(np.float64), axis=1)
+    m_ref = np.nanmean(ref[0:3].astype(np.float64), axis=1)
+    assert np.all(np.abs(m_gpu / m_ref - 1.0) < 1e-4)
+    # exposure on the GPU's own accumulators vs the oracle on the same planes
+    for f in (0, 1, 2):
+        e_gpu, raw_gpu = ctx.auto_exposure(f)
+        e_ref, raw_ref = oracle.auto_exposure(planes, 64, 36, 8, f)
+        assert abs(raw_gpu - raw_ref) <= 1e-9 * abs(raw_ref)
+        assert abs(e_gpu - e_ref) <= 2e-6 * abs(e_ref)
+
+
+def test_read_accumulators_uses_the_reference_layout(ctx):
+    import ptk
+    g = np.load(os.path.join(GOLDEN, "render_cornell_64x36.npz"))
+    ctx.set_constants(g["constants"].tobytes())
+    ctx.write_planes(g["acc_8spp"], 8)
+    acc = ctx.read_accumulators()
+    assert acc["sampleCount"] == 8
+    ref = g["acc_8spp"]
+    assert np.array_equal(acc["preScreen"], ref[0:3].T)
+    assert np.array_equal(acc["normal"], ref[3:6].T)
+    assert np.array_equal(acc["albedo1"], ref[6:9].T)
+    assert np.array_equal(acc["albedo2"], ref[9:12].T)
+    assert np.array_equal(acc["worldPos"], ref[12:15].T)
+    assert np.array_equal(acc["directLight"], ref[15])
+    assert np.array_equal(acc["stdDev"], ref[32:38].T)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("nwin", [1, 3])
+def test_denoiser_matches_golden(ctx, variant, nwin, oracle):
+    g = np.load(os.path.join(GOLDEN, "denoise_MultiLightGlass_128x72.npz"))
+    O = oracle
+    sc = O.load_scene(scene_path("MultiLightGlass"))
+    ctx.set_constants(O.build_constants(sc, 128, 72, 4, 0.005, True))
+    n = int(g["sample_count"])
+    ctx.write_planes(g["acc_8spp"], n)
+    w = O.load_weights(weights_path("BEST"))
+    r = ctx.denoise(w, nwin, variant, want_features=(variant == 0))
+    if variant == 0:
+        f, fr = r["features"], g["features36"]
+        for lo, hi in ((0, 15), (20, 25), (30, 36)):      # primaries, sd, mean7, Sobel, MAD, 1/spp
+            assert np.array_equal(f[:, lo:hi], fr[:, lo:hi])
+        assert _rel_ok(f[:, 15:20], fr[:, 15:20], 2e-5).all()  # 7x7 standard deviation
+        assert _rel_ok(f[:, 25:30], fr[:, 25:30], 2e-5).all()  # 3x3 mean deviation
+    assert _rel_ok(r["variances"], g["variances7"], 2e-5).all()
+    assert _rel_ok(r["denoised"], g["denoised_n%d" % nwin], 2e-5).all()
+    assert _rel_ok(r["wcSum"], g["wcsum_n%d" % nwin], 2e-5).all()
+
+
+def test_denoiser_odd_sizes_and_edges(ctx, oracle):
+    """Clamp-to-edge on an image that is not a multiple of the 16x16 tile."""
+    O = oracle
+    W, H = 37, 23
+    sc = O.load_scene(scene_path("cornell_crystal"))
+    consts = O.build_constants(sc, W, H, 4, 0.005, True)
+    acc = O.new_accumulators(W, H)
+    n, _, _ = O.render(consts, acc, 5, 0, PIN_SEED, threads=4)
+    w = O.load_weights(weights_path("box_grid"))
+    feats, var = O.forward_prop(acc, W, H, n, w)
+    ctx.set_constants(consts)
+    ctx.write_planes(acc, n)
+    for nwin in (0, 1, 2, 5):
+        den, wc = O.filter(acc, var, W, H, n, nwin)
+        for variant in (0, 1):
+            r = ctx.denoise(w, nwin, variant)
+            assert _rel_ok(r["variances"], var, 2e-5).all()
+            assert _rel_ok(r["denoised"], den, 5e-5).all()
+            assert _rel_ok(r["wcSum"], wc, 5e-5).all()
+
+
+def test_render_odd_sizes_depths_and_empty_scene(ctx, oracle):
+    import ptk
+    O = oracle
+    sc = O.load_scene(scene_path("bars3"))
+    for (W, H, depth) in ((1, 1, 4), (17, 9, 1), (33, 20, 7), (40, 30, 12)):
+        consts = O.build_constants(sc, W, H, depth, 0.005, True)
+        acc = O.new_accumulators(W, H)
+        n, glo, rays = O.render(consts, acc, 2, 0, PIN_SEED, threads=2)
+        ctx.set_constants(consts)
+        _, gglo = ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+        assert gglo == glo
+        planes = ctx.read_planes()
+        assert _rel_ok(planes, acc, 1e-4).all(axis=0).mean() >= 0.98
+    # no shapes: every ray misses and sees the sky gradient
+    consts = O.build_constants(sc, 32, 16, 4, 0.0, False)
+    consts.num_shapes = 0
+    consts.num_imp = 0
+    acc = O.new_accumulators(32, 16)
+    O.render(consts, acc, 1, 0, PIN_SEED)
+    ctx.set_constants(consts)
+    rays, _ = ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    assert rays == 32 * 16
+    assert np.array_equal(ctx.read_planes(0, 3), acc[0:3])
+
+
+def test_invalid_arguments_are_rejected(ctx, oracle):
+    import ptk
+    O = oracle
+    sc = O.load_scene(scene_path("cornell"))
+    consts = O.build_constants(sc, 32, 16, 4, 0.005, True)
+    with pytest.raises(ptk.PtkError):
+        ctx.set_constants(bytes(consts)[:-4])
+    bad = O.build_constants(sc, 32, 16, 4, 0.005, True)
+    bad.num_shapes = 51
+    with pytest.raises(ptk.PtkError):
+        ctx.set_constants(bad)
+    bad = O.build_constants(sc, 32, 16, 13, 0.005, True)
+    with pytest.raises(ptk.PtkError):
+        ctx.set_constants(bad)
+    bad = O.build_constants(sc, 32, 16, 4, 0.005, True)
+    bad.shapes[2][2] = 445          # 13 attributes would run past the 450-entry table
+    with pytest.raises(ptk.PtkError):
+        ctx.set_constants(bad)
+    ctx.set_constants(consts)
+    with pytest.raises(ptk.PtkError):
+        ctx.render(-1, ptk.SEED_COUNTER)
+    with pytest.raises(ptk.PtkError):
+        ctx.denoise(O.load_weights(weights_path("BEST")), 1, 0)   # nothing accumulated yet
+    rays, _ = ctx.render(0, ptk.SEED_COUNTER)
+    assert rays == 0 and ctx.sample_count == 0
+
+
+def test_counter_seeds_are_deterministic_and_additive(ctx, oracle):
+    """Full-size properties at 1080p: a call split in two equals one call, a repeat
+    reproduces it bit for bit, and different streams decorrelate."""
+    import ptk
+    O = oracle
+    W, H = 1920, 1080
+    sc = O.load_scene(scene_path("cornell_crystal"))
+    ctx.set_constants(O.build_constants(sc, W, H, 4, 0.005, True))
+    ctx.set_stream_id(0)
+    ctx.render(6, ptk.SEED_COUNTER)
+    a = ctx.read_planes()
+    ctx.reset()
+    ctx.render(2, ptk.SEED_COUNTER)
+    ctx.render(4, ptk.SEED_COUNTER)
+    b = ctx.read_planes()
+    assert np.array_equal(a, b, equal_nan=True)
+    ctx.reset()
+    ctx.set_stream_id(1)
+    ctx.render(6, ptk.SEED_COUNTER)
+    c = ctx.read_planes(0, 3)
+    ctx.set_stream_id(0)
+    assert not np.array_equal(a[0:3], c)
+    ma = np.nanmean(a[0:3].astype(np.float64)) / 6
+    mc = np.nanmean(c.astype(np.float64)) / 6
+    assert abs(ma / mc - 1.0) < 5e-3     # two independent 12 M-sample estimates of one mean
+    e, raw = ctx.auto_exposure(2)
+    assert raw > 0 and np.isfinite(e)
+
+
+def test_counter_seeded_image_converges_to_the_reference_seeded_one(ctx, oracle):
+    """RMSE bound: 64 spp with device seeds against 64 spp with the reference's seed
+    stream, both on the GPU, and the latter against the oracle's mean."""
+    import ptk
+    O = oracle
+    W, H = 160, 90
+    sc = O.load_scene(scene_path("cornell_crystal"))
+    consts = O.build_constants(sc, W, H, 4, 0.005, False)
+    acc = O.new_accumulators(W, H)
+    O.render(consts, acc, 64, 0, PIN_SEED, threads=8)
+    ctx.set_constants(consts)
+    ctx.render(64, ptk.SEED_REFERENCE, PIN_SEED)
+    ref_seeded = ctx.read_planes(0, 3) / 64
+    ctx.reset()
+    ctx.render(64, ptk.SEED_COUNTER)
+    ctr_seeded = ctx.read_planes(0, 3) / 64
+    orc = acc[0:3] / 64
+    # same seeds: means agree to 1e-4; different seeds: within Monte Carlo noise
+    assert abs(np.nanmean(ref_seeded) / np.nanmean(orc) - 1.0) < 1e-4
+    assert abs(np.nanmean(ctr_seeded) / np.nanmean(orc) - 1.0) < 2e-2
+    noise = np.sqrt(np.nanmean((ref_seeded - orc) ** 2))
+    rmse = np.sqrt(np.nanmean((ctr_seeded - orc) ** 2))
+    spread = np.sqrt(np.nanmean(orc ** 2))
+    assert noise < 0.02 * spread      # matched seeds: only a few diverged paths
+    assert rmse < 1.0 * spread        # independent seeds at 64 spp: bounded by the estimator noise
