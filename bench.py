@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-trace hot path on MI355X.
+
+A step is one ptk_render call of --spp-per-step samples per pixel on
+cornell_crystal at 1920x1080 (BASELINE.json configs[1]: 2000 spp, render only;
+the default 10 steps x 200 spp are exactly that job).  The accumulators live in
+HBM for the whole run and seeds are generated on the device, so nothing crosses
+PCIe inside the timed region.  With N > 1 ranks every rank renders the same
+number of samples of every pixel on its own seed stream (weak scaling) and each
+step ends with the per-frame accumulation all-reduce over RCCL.
+
+Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import multigpu  # noqa: E402
+import ptk  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X vector fp32 peak (FMA = 2 flop)
+PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
+
+
+def load_opcount(scene):
+    """Algorithmic operations per sample, counted by the op-counting build of the CPU
+    restatement (profiles/opcount.json, written by scripts/count_ops.py)."""
+    path = os.path.join(ROOT, "profiles", "opcount.json")
+    with open(path) as f:
+        table = json.load(f)
+    return table[scene]
+
+
+def cpu_baseline(scene, W, H, depth):
+    """The CPU oracle timed on the host cores: a bounded sample of the same workload."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    threads = max(1, min(threads, 16))
+    sc = O.load_scene(os.path.join(ROOT, "data", "scenes", scene + ".scene"))
+    consts = O.build_constants(sc, W, H, depth, 0.005, False)
+    acc = O.new_accumulators(W, H)
+    seed = (0x9E3779B97F4A7C15, 0xD1B54A32D192ED03)
+    O.render(consts, acc, 1, 0, seed, threads=threads)      # warm (page in, spawn the team)
+    spp = 4
+    t0 = time.perf_counter()
+    O.render(consts, acc, spp, 1, seed, threads=threads)
+    dt = time.perf_counter() - t0
+    # keep the whole leg near 10-30 s: extend once if the first sample was short
+    if dt < 5.0:
+        more = int(min(32, max(4, spp * 10.0 / max(dt, 1e-3))))
+        t0 = time.perf_counter()
+        O.render(consts, acc, more, 1 + spp, seed, threads=threads)
+        dt = time.perf_counter() - t0
+        spp = more
+    return {
+        "value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": "%s %dx%d, %d spp, maxDepth %d, OpenMP over rows with pre-generated "
+                  "reference seeds (oracle/ptk_oracle.c)" % (scene, W, H, spp, depth),
+    }
+
+
+def denoise_probe(ctx, W, H, depth):
+    """BASELINE.json configs[2]: MultiLightGlass 1080p, 128 spp, BEST.txt, N = 1."""
+    raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", "MultiLightGlass.scene"),
+                                    W, H, depth, 0.005, True)
+    w = ptk.load_weights(os.path.join(ROOT, "data", "weights", "BEST.txt"))
+    ctx.set_constants(raw)
+    ctx.render(128, ptk.SEED_COUNTER)
+    render_ms = ctx.timing().render_ms
+    out = {"workload": "MultiLightGlass %dx%d 128 spp + denoise N=1 BEST.txt" % (W, H),
+           "render_msamples_per_s": W * H * 128 / render_ms / 1e3}
+    for variant, name in ((0, "two_pass"), (1, "fused")):
+        ts = []
+        for _ in range(12):
+            ctx.denoise(w, 1, variant, want_outputs=False)
+            t = ctx.timing()
+            ts.append((t.denoise_ms, t.features_ms, t.filter_ms))
+        ts = ts[2:]
+        avg = [sum(x[i] for x in ts) / len(ts) for i in range(3)]
+        out[name + "_ms"] = avg[0]
+        if variant == 0:
+            out["features_ms"], out["filter_ms"] = avg[1], avg[2]
+            out["features_gbs"] = W * H * 100 / avg[1] / 1e6
+            out["filter_gbs"] = W * H * 132 / avg[2] / 1e6
+        else:
+            out["fused_gbs"] = W * H * 104 / avg[0] / 1e6
+    es = []
+    for _ in range(12):
+        ctx.auto_exposure(ptk.EXPOSURE_CPU)
+        es.append(ctx.timing().exposure_ms)
+    e = sum(es[2:]) / len(es[2:])
+    out["exposure_ms"] = e
+    out["exposure_gbs"] = W * H * 12 / e / 1e6
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=200)
+    ap.add_argument("--scene", default="cornell_crystal")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--math", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-denoise-probe", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libptk has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    W, H = args.width, args.height
+    ctx = ptk.Context(local_rank)
+    raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", args.scene + ".scene"),
+                                    W, H, args.depth, 0.005, False)
+    ctx.set_constants(raw)
+    ctx.set_math_mode(ptk.MATH_FAST if args.math == "fast" else ptk.MATH_EXACT)
+    ctx.set_stream_id(rank)
+    planes = multigpu.device_planes(ctx, device) if world > 1 else None
+    frame = torch.empty((3, W * H), dtype=torch.float32, device=device) if world > 1 else None
+
+    spp = args.spp_per_step
+    kernel_ms = []
+
+    def step():
+        ctx.render(spp, ptk.SEED_COUNTER)
+        kernel_ms.append(ctx.timing().render_ms)
+        if world > 1:
+            # per-frame accumulation exchange: sum of the colour planes over ranks
+            frame.copy_(planes[0:3])
+            dist.all_reduce(frame)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_total = float(W) * H * spp * args.steps * world
+    value = samples_total / elapsed / 1e6
+    out = {
+        "metric": "Msamples/sec (paths/s) cornell_crystal 1080p",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "Scenes/%s.scene %dx%d, %d spp per step x %d steps per GPU, render only, "
+                        "maxDepth %d, device counter seeds, math=%s" % (
+                            args.scene, W, H, spp, args.steps, args.depth, args.math),
+            "samples_per_step_per_gpu": W * H * spp,
+            "exchange": "all-reduce of 3 colour planes per step" if world > 1 else "none",
+        },
+    }
+    if rank == 0:
+        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        samples_per_launch = float(W) * H * spp
+        try:
+            ops = load_opcount(args.scene)
+            flops = ops["flops_per_sample"]
+            achieved = samples_per_launch * flops / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "valu", "kernel": "render_kernel", "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": None, "avg_launch_ms": avg_ms,
+                "flops_per_sample": flops, "int_ops_per_sample": ops.get("int_ops_per_sample"),
+                "note": "fp32 VALU bound (not HBM, not MFMA): algorithmic flops per sample from "
+                        "the op-counting build of the CPU restatement",
+            }
+        except (OSError, KeyError) as exc:
+            out["roofline"] = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_TFLOPS,
+                               "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "avg_launch_ms": avg_ms, "note": "op count unavailable: %s" % exc}
+        if world == 1:
+            if not args.no_denoise_probe:
+                out["denoise"] = denoise_probe(ctx, W, H, args.depth)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

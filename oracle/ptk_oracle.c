@@ -43,6 +43,29 @@ typedef float lm_t;
 #endif
 static const float EPS = 0.00001f;    /* Renderers.cpp:113 */
 
+/* Op-counting build (-DORC_COUNT_OPS, single-threaded): tallies the algorithmic
+ * work of the render path as written in the reference -- fp add/sub/mul/div/
+ * sqrt/convert as flops, 64-bit integer RNG operations as two 32-bit integer
+ * ops each, and libm calls (cos, sin, acos, pow) separately.  Comparisons,
+ * selects and loads are not counted. */
+#ifdef ORC_COUNT_OPS
+static uint64_t g_flops, g_iops, g_libm, g_shape_tests, g_samples;
+#define OPS(n) (g_flops += (n))
+#define IOPS(n) (g_iops += (n))
+#define LIBM(n) (g_libm += (n))
+#define SHAPE_TEST() (g_shape_tests += 1)
+void orc_opcount_reset(void) { g_flops = g_iops = g_libm = g_shape_tests = g_samples = 0; }
+void orc_opcount_get(uint64_t out[5])
+{
+    out[0] = g_flops; out[1] = g_iops; out[2] = g_libm; out[3] = g_shape_tests; out[4] = g_samples;
+}
+#else
+#define OPS(n) ((void)0)
+#define IOPS(n) ((void)0)
+#define LIBM(n) ((void)0)
+#define SHAPE_TEST() ((void)0)
+#endif
+
 /* ------------------------------------------------------------------ RNG */
 
 /* Global seed step, Renderers.cpp:832-838.  The OR binds the whole
@@ -67,6 +90,8 @@ void orc_seed_stream(uint64_t glo[2], size_t n, int64_t* out_pairs)
 /* randBetween, Renderers.cpp:12-24: xoroshiro128++ output, u64 -> f64 -> f32. */
 float orc_rand_between(int64_t state[2], float lo, float hi)
 {
+    IOPS(30);
+    OPS(6);
     uint64_t a = (uint64_t)state[0];
     uint64_t b = (uint64_t)state[1];
     uint64_t sum = a + b;
@@ -85,11 +110,13 @@ float orc_rand_between(int64_t state[2], float lo, float hi)
 
 static inline float dot3(const float* a, const float* b)
 {
+    OPS(5);
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
 static inline void normalize3(float* v)
 {
+    OPS(4);
     lm_t len = LM_SQRT(dot3(v, v));
     v[0] /= len;
     v[1] /= len;
@@ -100,6 +127,7 @@ static inline void normalize3(float* v)
  * (Renderers.cpp:25-39, headers/Obj.h:26-40); components are w,x,y,z. */
 static void quat_mul(float* lhs, const float* rhs)
 {
+    OPS(36);
     float a1 = (lhs[3] + lhs[1]) * (rhs[1] + rhs[2]);
     float a3 = (lhs[0] - lhs[2]) * (rhs[0] + rhs[3]);
     float a4 = (lhs[0] + lhs[2]) * (rhs[0] - rhs[3]);
@@ -116,6 +144,7 @@ static void quat_mul(float* lhs, const float* rhs)
 /* v <- conj(q) * (v * q), Renderers.cpp:40-47. */
 static void quat_rotate(float* v, const float* q)
 {
+    OPS(3);
     float p[4] = {0.0f, v[0], v[1], v[2]};
     float qc[4] = {q[0], -q[1], -q[2], -q[3]};
     quat_mul(p, q);
@@ -130,6 +159,8 @@ static void quat_rotate(float* v, const float* q)
 static float box_distance(const float* a, const float* origin, const float* dir,
                           float* rpos, float* rdir)
 {
+    SHAPE_TEST();
+    OPS(3 + 3 + 8); /* to box space and back, x and y slabs */
     rdir[0] = dir[0]; rdir[1] = dir[1]; rdir[2] = dir[2];
     float centre[3] = {a[0], a[1], a[2]};
     rpos[0] = origin[0] - centre[0];
@@ -153,6 +184,7 @@ static float box_distance(const float* a, const float* origin, const float* dir,
         return INFINITY;
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmax) tmax = tymax;
+    OPS(4);
     float tzmin = (lohi[neg[2]][2] - rpos[2]) / rdir[2];
     float tzmax = (lohi[1 - neg[2]][2] - rpos[2]) / rdir[2];
     if ((tmin > tzmax) || (tzmin > tmax))
@@ -167,12 +199,16 @@ static float box_distance(const float* a, const float* origin, const float* dir,
 /* Geometric sphere test, Renderers.cpp:179-200 and 551-568. */
 static float sphere_distance(const float* a, const float* origin, const float* dir)
 {
+    SHAPE_TEST();
+    OPS(3);
     float l[3] = {a[0] - origin[0], a[1] - origin[1], a[2] - origin[2]};
     float tca = dot3(l, dir);
     if (tca < EPS) return INFINITY;
+    OPS(4);
     float dsq = dot3(l, l) - tca * tca;
     float rsq = a[3] * a[3];
     if (rsq - dsq < EPS) return INFINITY;
+    OPS(4);
     float thc = sqrtf(rsq - dsq);
     float t0 = tca - thc;
     float t1 = tca + thc;
@@ -190,6 +226,7 @@ static void box_normal(const float* a, const float* obb_hit, const float* dir,
     const float* lo = a + 3;
     const float* hi = a + 6;
     float thr = shadow_variant ? 0.0f : EPS;
+    OPS(8); /* on average four |a-b| tests before a face matches */
     n[0] = n[1] = n[2] = 0.0f;
     if (fabsf(lo[0] - hi[0]) < EPS)      n[0] = dir[0] > thr ? -1 : 1;
     else if (fabsf(lo[1] - hi[1]) < EPS) n[1] = dir[1] > thr ? -1 : 1;
@@ -209,6 +246,8 @@ static void box_normal(const float* a, const float* obb_hit, const float* dir,
  * (Renderers.cpp:358-365, 400-407, 640-647): two draws. */
 static void blur_direction(int64_t* rng, float* out)
 {
+    OPS(4 + 3);
+    LIBM(7);
     float u = orc_rand_between(rng, 0, 1.0f);
     float a = (float)((double)LM_ACOS(2.0f * u - 1.0f) - ORC_PI / 2.0);
     float b = orc_rand_between(rng, 0, (float)(2.0 * ORC_PI));
@@ -221,6 +260,7 @@ static void blur_direction(int64_t* rng, float* out)
  * (Renderers.cpp:374, 387, 417, 782). */
 static inline float cos_over_pi(float c)
 {
+    OPS(1);
     return c < 0.00001f ? 0.00001f : (float)((double)c / ORC_PI);
 }
 
@@ -231,6 +271,10 @@ void orc_render_sample(const orc_constants* c, int row, int col,
                        int64_t s1, int64_t s2, orc_sample* out)
 {
     int64_t rng[2] = {s1, s2};
+#ifdef ORC_COUNT_OPS
+    g_samples++;
+#endif
+    OPS(2 + 14 + 27); /* jitter scale, pixel angles, pixel position */
 
     float jitter[2] = {0.0f, 0.0f};
     if (c->rand_samp > 0.001f) {
@@ -290,6 +334,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
             if (type == 1) {
                 t = box_distance(c->attrs + a, origin, dir, rpos, rdir);
                 if (t < best) {
+                    OPS(6);
                     obb_hit[0] = rpos[0] + rdir[0] * t;
                     obb_hit[1] = rpos[1] + rdir[1] * t;
                     obb_hit[2] = rpos[2] + rdir[2] * t;
@@ -298,6 +343,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
                 t = sphere_distance(c->attrs + a, origin, dir);
             }
             if (t < best) {
+                OPS(6);
                 best = t;
                 p[0] = origin[0] + dir[0] * t;
                 p[1] = origin[1] + dir[1] * t;
@@ -307,6 +353,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
         }
 
         if (shape < 0) { /* miss, Renderers.cpp:739-744 */
+            OPS(3);
             back[0] = 0.1f;
             back[1] = 0.1f;
             back[2] = (dir[1] + 1.0f) / 2.2f + 0.1f;
@@ -317,12 +364,15 @@ void orc_render_sample(const orc_constants* c, int row, int col,
         if (shape_type == 1) {
             box_normal(c->attrs + attr, obb_hit, dir, 0, n);
         } else {
+            OPS(3);
             n[0] = p[0] - c->attrs[attr + 0];
             n[1] = p[1] - c->attrs[attr + 1];
             n[2] = p[2] - c->attrs[attr + 2];
             normalize3(n);
         }
 
+        OPS(1 + 9 + 2 + 3 + 1 + 2 + 15); /* basis, phi, radii, local-to-world */
+        LIBM(2);
         /* five draws and the cosine-weighted direction (Renderers.cpp:273-312) */
         float u[5];
         for (int k = 0; k < 5; k++) u[k] = orc_rand_between(rng, 0, 1);
@@ -349,6 +399,8 @@ void orc_render_sample(const orc_constants* c, int row, int col,
         float mat_type = c->mats[mat][5];
         if (mat_type == 3) {
             /* dielectric, Renderers.cpp:328-389 */
+            OPS(1 + 3 + 4 + 1 + 4 + 5 + 19);
+            LIBM(1);
             lit[depth] = 1;
             float blur = c->mats[mat][3];
             float eta = 1.0f / c->mats[mat][4];
@@ -381,6 +433,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
             pdf[depth] = cos_over_pi(dot3(n, dir));
         } else if (mat_type == 2) {
             /* metal, Renderers.cpp:390-418 */
+            OPS(13);
             lit[depth] = 1;
             float in[3] = {dir[0], dir[1], dir[2]};
             float blur = c->mats[mat][3];
@@ -401,6 +454,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
             } else {
                 mix = c->num_imp > 0;
                 if (mix) {
+                    OPS(3);
                     int pick = (int)(u[3] * c->num_imp * 0.99999f);
                     target = (int)c->imp[pick];
                     if (target == shape) mix = 0;
@@ -413,6 +467,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
                 const float* ta = c->attrs + t_attr;
                 if (u[4] > 0.65f) {
                     float aim[3] = {0.0f, 0.0f, 0.0f};
+                    OPS(12 + 3 + 1 + 3 + 1 + 1); /* aim point, direction, length, cosine test, p0 */
                     if (t_type == 1) {
                         float w[3];
                         for (int k = 0; k < 3; k++) w[k] = orc_rand_between(rng, 0, 1);
@@ -462,6 +517,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
                             if ((int)c->mats[smat][5] == 3) {
                                 /* a dielectric occluder bends the shadow ray; the
                                  * normal is taken from the SHADED surface's shape */
+                                OPS(1 + 6 + 3 + 5 + 19);
                                 float blur = c->mats[smat][3];
                                 float eta = 1.0f / c->mats[smat][4];
                                 float rn[3] = {0.0f, 0.0f, 0.0f};
@@ -511,6 +567,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
                     }
                 }
                 float p1 = 0;
+                OPS(t_type == 1 ? 12 + 3 + 1 + 2 + 3 : 3 + 2 + 1 + 1 + 1 + 2 + 1 + 2 + 1 + 3);
                 if (t_type == 1) {
                     float area = 0;
                     float dx = ta[3] - ta[6];
@@ -556,6 +613,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
             out_dir[2] = hit_pos[k + 1][2] - hit_pos[k][2];
             normalize3(out_dir);
         }
+        OPS((k == n_hits - 1 ? 0 : 3) + 1 + 12);
         float scatter = cos_over_pi(dot3(hit_n[k], out_dir));
         float boost = (lit[k] == 1 && c->num_imp > 1) ? (float)c->num_imp : 1.0f;
         float ratio = scatter / pdf[k];
@@ -584,6 +642,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
             const float* m2 = c->mats[c->shapes[hit_shape[1]][1]];
             out->albedo2[0] = m2[0]; out->albedo2[1] = m2[1]; out->albedo2[2] = m2[2];
         }
+        OPS(3 * c->max_depth);
         out->direct_light = 0.0f;
         for (int k = 0; k < c->max_depth; k++)
             out->direct_light += (float)lit[k] / (float)c->max_depth;
@@ -599,6 +658,7 @@ static void accumulate_pixel(const orc_constants* c, float* acc, size_t P, size_
                              const orc_sample* s, int sample_count)
 {
     float n = (float)sample_count;
+    OPS(c->want_features == 1 ? 3 + 13 + 64 + 18 : 3);
     acc[(ORC_PL_COL + 0) * P + i] += s->xyz[0];
     acc[(ORC_PL_COL + 1) * P + i] += s->xyz[1];
     acc[(ORC_PL_COL + 2) * P + i] += s->xyz[2];

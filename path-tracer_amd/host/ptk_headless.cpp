@@ -1,0 +1,118 @@
+// ptk_headless.cpp -- headless driver: the reference's frame loop
+// (PT.cpp:105-131) without the window.  Loads a scene, renders, optionally
+// auto-exposes and denoises, and writes a PPM and/or raw float dumps.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "ptk_host.h"
+
+using namespace ptkhost;
+
+static void usage()
+{
+    std::fprintf(stderr,
+                 "usage: ptk_headless --scene FILE [--res WxH] [--spp N] [--depth D]\n"
+                 "       [--rand-samp F] [--seed HEX0,HEX1 | --counter-seeds] [--fast]\n"
+                 "       [--auto-exposure] [--denoise N --weights FILE] [--device K]\n"
+                 "       [--ppm OUT.ppm] [--dump PREFIX]\n");
+}
+
+static bool dump(const std::string& path, const std::vector<float>& v)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char*)v.data(), (std::streamsize)(v.size() * sizeof(float)));
+    return (bool)f;
+}
+
+int main(int argc, char** argv)
+{
+    std::string scene, weights, ppm, prefix;
+    int W = 1536, H = 864, spp = 16, depth = 4, nwin = -1, device = 0;
+    float rand_samp = 0.005f;
+    bool counter = false, fast = false, auto_exp = false, have_seed = false;
+    uint64_t seed[2] = {0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull};
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--scene") scene = next();
+        else if (a == "--res") { if (std::sscanf(next(), "%dx%d", &W, &H) != 2) { usage(); return 2; } }
+        else if (a == "--spp") spp = std::atoi(next());
+        else if (a == "--depth") depth = std::atoi(next());
+        else if (a == "--rand-samp") rand_samp = (float)std::atof(next());
+        else if (a == "--seed") {
+            unsigned long long s0, s1;
+            if (std::sscanf(next(), "%llx,%llx", &s0, &s1) != 2) { usage(); return 2; }
+            seed[0] = s0; seed[1] = s1; have_seed = true;
+        }
+        else if (a == "--counter-seeds") counter = true;
+        else if (a == "--fast") fast = true;
+        else if (a == "--auto-exposure") auto_exp = true;
+        else if (a == "--denoise") nwin = std::atoi(next());
+        else if (a == "--weights") weights = next();
+        else if (a == "--device") device = std::atoi(next());
+        else if (a == "--ppm") ppm = next();
+        else if (a == "--dump") prefix = next();
+        else { usage(); return 2; }
+    }
+    if (scene.empty()) { usage(); return 2; }
+
+    HostState st;
+    st.device = device;
+    st.xRes = W; st.yRes = H; st.maxDepth = depth; st.randSamp = rand_samp;
+    st.denoising = nwin >= 0;
+    st.denoisingN = nwin >= 0 ? nwin : 1;
+    st.seedMode = counter ? PTK_SEED_COUNTER : PTK_SEED_REFERENCE;
+    st.mathMode = fast ? PTK_MATH_FAST : PTK_MATH_EXACT;
+    if (!st.scene.LoadScene(scene)) return 1;
+    st.renderer.UpdateConstants();
+    if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
+    if (have_seed || !counter) { st.renderer.GloRandS[0] = seed[0]; st.renderer.GloRandS[1] = seed[1]; }
+
+    st.renderer.Render(spp);
+    if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
+    std::printf("render: %dx%d %d spp  %.3f ms  %.1f Msamples/s  %llu rays\n", W, H, spp,
+                st.renderTime, (double)W * H * spp / st.renderTime / 1e3,
+                (unsigned long long)st.rayCount);
+    if (auto_exp) {
+        st.renderer.AutoExposure();
+        if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
+        std::printf("auto exposure: %.9g (%.4f ms)\n", st.exposure, st.exposureTime);
+    }
+    bool denoised = false;
+    if (nwin >= 0) {
+        if (weights.empty() || !st.denoiserNN.LoadWeights(weights)) {
+            std::fprintf(stderr, "--denoise needs --weights FILE\n");
+            return 1;
+        }
+        st.denoiser.denoise();
+        if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
+        std::printf("denoise: N=%d  %.4f ms\n", st.denoisingN, st.denoiseTime);
+        denoised = true;
+    }
+    st.SyncScreens();
+    if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
+    if (!prefix.empty()) {
+        dump(prefix + ".preScreen.f32", st.preScreen);
+        if (st.denoising) {
+            dump(prefix + ".normal.f32", st.normal);
+            dump(prefix + ".albedo1.f32", st.albedo1);
+            dump(prefix + ".albedo2.f32", st.albedo2);
+            dump(prefix + ".worldPos.f32", st.worldPos);
+            dump(prefix + ".directLight.f32", st.directLight);
+            dump(prefix + ".stdDev.f32", st.stdDev);
+        }
+        if (denoised) {
+            dump(prefix + ".denoisedCol.f32", st.denoisedCol);
+            dump(prefix + ".variances.f32", st.variances);
+            dump(prefix + ".wcSum.f32", st.wcSum);
+        }
+    }
+    if (!ppm.empty()) {
+        st.PostProcess(denoised);
+        if (!st.SaveImage(ppm)) { std::fprintf(stderr, "cannot write %s\n", ppm.c_str()); return 1; }
+    }
+    return 0;
+}

@@ -215,3 +215,49 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.ptk_synchronize(self._h))
+
+
+# ---- host facade helpers (libptk_host.so: the product's own scene / weight loaders) ----
+
+HOST_LIB_PATH = os.path.join(_HERE, "libptk_host.so")
+_host = None
+
+
+def _load_host():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise PtkError("libptk_host.so not found at %s: build it with "
+                           "`make -C path-tracer_amd`" % HOST_LIB_PATH)
+        load()  # libptk_host.so depends on libptk.so
+        H = C.CDLL(HOST_LIB_PATH)
+        H.ptkhost_scene_constants.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                              C.c_int, C.c_void_p, C.POINTER(C.c_float),
+                                              C.POINTER(C.c_float)]
+        H.ptkhost_scene_constants.restype = C.c_int
+        H.ptkhost_load_weights.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float)]
+        H.ptkhost_load_weights.restype = C.c_int
+        _host = H
+    return _host
+
+
+def scene_constants(path, width, height, max_depth=4, rand_samp=0.005, denoising=False):
+    """Scene file -> (3732-byte POD, exposure, gamma) via Scene::LoadScene + UpdateConstants."""
+    buf = C.create_string_buffer(CONSTANTS_BYTES)
+    e, g = C.c_float(0), C.c_float(0)
+    rc = _load_host().ptkhost_scene_constants(os.fsencode(path), width, height, max_depth,
+                                              C.c_float(rand_samp), int(bool(denoising)), buf,
+                                              C.byref(e), C.byref(g))
+    if rc != 0:
+        raise PtkError("cannot load scene %s" % path)
+    return buf.raw, float(e.value), float(g.value)
+
+
+def load_weights(path):
+    """Weights file -> (w12[360], w23[100], w34[70]) via DenoiserNN::LoadWeights."""
+    w12, w23, w34 = np.zeros(360, np.float32), np.zeros(100, np.float32), np.zeros(70, np.float32)
+    rc = _load_host().ptkhost_load_weights(os.fsencode(path), _fp(w12), _fp(w23), _fp(w34))
+    if rc != 0:
+        raise PtkError("cannot load weights %s" % path)
+    return w12, w23, w34
