@@ -179,6 +179,8 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
             o.rotated = (at[10] + at[11] + at[12] > E) ? 1 : 0;
             for (int i = 2; i >= 0; i--)
                 if (std::fabs(o.lo[i] - o.hi[i]) < E) o.flat_axis = i;
+            for (int i = 0; i < 3; i++)
+                if (o.lo[i] == o.hi[i]) o.same_mask |= 1 << i;
             // importance pdf area (Renderers.cpp:691-697)
             float dx = at[3] - at[6], dy = at[4] - at[7], dz = at[5] - at[8];
             float area = 0;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptk.so")
+LIB_PATH = os.environ.get("PTK_LIB") or os.path.join(_HERE, "libptk.so")
 
 CONSTANTS_BYTES = 3732
 N_PLANES = 38
