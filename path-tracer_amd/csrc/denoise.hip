@@ -25,21 +25,27 @@ DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896
 DEV float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// x / n, bit-identical to the IEEE quotient: an exact reciprocal multiply when
-// n is a power of two, the correctly rounded division otherwise.
-struct DivN {
-    float n, inv;
-    bool pow2;
-    DEV float operator()(float x) const { return pow2 ? x * inv : x / n; }
-};
-DEV DivN make_divn(float n)
+// x / d for many x and one d, bit-identical to the IEEE quotient.  hipcc's
+// correctly rounded division is: (scale operands: identity unless an exponent
+// is extreme) r = rcp(d), one Newton step on r, q = x*r, two residual
+// corrections, v_div_fixup.  The first three operations depend on d only and
+// are shared here.  Denominators in this file are sample counts, 3*count, 49
+// and 9, all far inside the range where no scaling happens.
+struct Recip { float r, d; };
+DEV Recip make_recip(float d)
 {
-    DivN d;
-    d.n = n;
-    int bits = __float_as_int(n);
-    d.pow2 = (bits & 0x007fffff) == 0;
-    d.inv = 1.0f / n;
-    return d;
+    float r0 = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r0, 1.0f);
+    return {__builtin_fmaf(e, r0, r0), d};
+}
+DEV float div_by(float x, const Recip& R)
+{
+    float q = x * R.r;
+    float t = __builtin_fmaf(-R.d, q, x);
+    q = __builtin_fmaf(t, R.r, q);
+    t = __builtin_fmaf(-R.d, q, x);
+    q = __builtin_fmaf(t, R.r, q);
+    return __builtin_amdgcn_div_fixupf(q, R.d, x);
 }
 
 // The reference's "median getter" procedure (DenoiserNN.cpp:190-256), literal,
@@ -96,12 +102,12 @@ DEV float mad_procedure(float (&v)[9])
 
 // Primary feature of one pixel (DenoiserNN.cpp:16-36): three separate
 // quotients summed in order, bit-exact.
-DEV float primary3(const float* __restrict__ p, size_t P, size_t i, float three_n)
+DEV float primary3(const float* __restrict__ p, size_t P, size_t i, const Recip& three_n)
 {
     float v = 0.0f;
-    v += p[i] / three_n;
-    v += p[P + i] / three_n;
-    v += p[2 * P + i] / three_n;
+    v += div_by(p[i], three_n);
+    v += div_by(p[P + i], three_n);
+    v += div_by(p[2 * P + i], three_n);
     return v;
 }
 #pragma clang fp contract(fast)
@@ -120,26 +126,40 @@ DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 
 // 36 features + MLP for the pixel at tile coordinates (ly, lx) of an LDS tile
-// of primaries `t` laid out [5][FT][FT_PITCH].
-DEV void features_and_mlp(const float* t, int ly, int lx, const float* sd5, float inv_spp,
-                          const __attribute__((address_space(4))) float* w, float (&f)[36],
+// `t` laid out [15][FT][FT_PITCH]: the primaries q, then q/49, then q/9 (the
+// terms the reference adds up for its 7x7 and 3x3 means, each rounded once).
+//
+// The five feature channels are processed one after another in a rolled loop
+// and each channel's seven features are folded into the ten first-layer sums
+// as soon as they exist, so the live state is ten accumulators rather than 36
+// features (the first layer's summation order differs from the reference's
+// index order; the MLP is compared within a tolerance either way).
+// Feature index of group g (0 value, 1 sd, 2 mean7, 3 sd7, 4 gradient,
+// 5 mean deviation, 6 "MAD") and channel k is 5*g + k; index 35 is 1/spp.
+DEV void features_and_mlp(const float* t, int ly, int lx, const float* __restrict__ planes, size_t P,
+                          size_t idx, float inv_spp,
+                          const __attribute__((address_space(4))) float* w, float* features_out,
                           float (&var)[7])
 {
+    float a1[10];
 #pragma unroll
+    for (int nd = 0; nd < 10; nd++) a1[nd] = inv_spp * w[36 * nd + 35];
+
+#pragma unroll 1
     for (int k = 0; k < 5; k++) {
         const float* tk = t + k * FT * FT_PITCH;
-        f[k] = tk[(ly + FH) * FT_PITCH + lx + FH];
-        f[5 + k] = sd5[k];
+        const float* tk49 = tk + 5 * FT * FT_PITCH;
+        const float* tk9 = tk + 10 * FT * FT_PITCH;
+        float fk[7];
+        fk[0] = tk[(ly + FH) * FT_PITCH + lx + FH];
+        fk[1] = planes[(size_t)(PTK_PL_SD + 1 + k) * P + idx];
 
         // 7x7 mean: the reference adds q/49 term by term in row-major order
         float mean7 = 0.0f;
-        {
-#pragma clang fp contract(off)
 #pragma unroll
-            for (int j = 0; j < 7; j++)
+        for (int j = 0; j < 7; j++)
 #pragma unroll
-                for (int i = 0; i < 7; i++) mean7 += tk[(ly + j) * FT_PITCH + lx + i] / 49.0f;
-        }
+            for (int i = 0; i < 7; i++) mean7 += tk49[(ly + j) * FT_PITCH + lx + i];
         // 7x7 standard deviation about that mean
         float ss = 0.0f;
 #pragma unroll
@@ -149,39 +169,53 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float* sd5, floa
                 float d = tk[(ly + j) * FT_PITCH + lx + i] - mean7;
                 ss = __builtin_fmaf(d, d, ss);
             }
-        f[10 + k] = mean7;
-        f[15 + k] = __builtin_sqrtf(ss * (1.0f / 49.0f));
+        fk[2] = mean7;
+        fk[3] = __builtin_sqrtf(ss * (1.0f / 49.0f));
 
         float win[9];
+        float mean3 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; j++)
 #pragma unroll
-            for (int i = 0; i < 3; i++) win[j * 3 + i] = tk[(ly + FH - 1 + j) * FT_PITCH + lx + FH - 1 + i];
-        float gx, gy, mean3 = 0.0f;
+            for (int i = 0; i < 3; i++) {
+                const int o = (ly + FH - 1 + j) * FT_PITCH + lx + FH - 1 + i;
+                win[j * 3 + i] = tk[o];
+                mean3 += tk9[o];
+            }
         {
 #pragma clang fp contract(off)
             // Sobel sums in the reference's accumulation order; zero taps add +-0
-            gx = 0.0f; gx += win[0]; gx += 2.0f * win[1]; gx += win[2];
+            float gx = 0.0f, gy = 0.0f;
+            gx += win[0]; gx += 2.0f * win[1]; gx += win[2];
             gx += 0.0f * win[3]; gx += 0.0f * win[4]; gx += 0.0f * win[5];
             gx += -1.0f * win[6]; gx += -2.0f * win[7]; gx += -1.0f * win[8];
-            gy = 0.0f; gy += win[0]; gy += 0.0f * win[1]; gy += -1.0f * win[2];
+            gy += win[0]; gy += 0.0f * win[1]; gy += -1.0f * win[2];
             gy += 2.0f * win[3]; gy += 0.0f * win[4]; gy += -2.0f * win[5];
             gy += win[6]; gy += 0.0f * win[7]; gy += -1.0f * win[8];
-            f[20 + k] = __builtin_sqrtf(gx * gx + gy * gy);
-#pragma unroll
-            for (int i = 0; i < 9; i++) mean3 += win[i] / 9.0f;
+            fk[4] = __builtin_sqrtf(gx * gx + gy * gy);
         }
         float md = 0.0f;
 #pragma unroll
         for (int i = 0; i < 9; i++) md += __builtin_fabsf(win[i] - mean3) * (1.0f / 9.0f);
-        f[25 + k] = md;
-        f[30 + k] = mad_procedure(win);
+        fk[5] = md;
+        fk[6] = mad_procedure(win);
+
+#pragma unroll
+        for (int g = 0; g < 7; g++) {
+            const auto* wg = w + 5 * g + k;
+#pragma unroll
+            for (int nd = 0; nd < 10; nd++) a1[nd] = __builtin_fmaf(fk[g], wg[36 * nd], a1[nd]);
+        }
+        if (features_out) {
+#pragma unroll
+            for (int g = 0; g < 7; g++) features_out[(size_t)(5 * g + k) * P + idx] = fk[g];
+        }
     }
-    f[35] = inv_spp;
+    if (features_out) features_out[(size_t)35 * P + idx] = inv_spp;
 
     float l2[10], l3[10];
 #pragma unroll
-    for (int nd = 0; nd < 10; nd++) l2[nd] = sigmoid(dot_w<36>(f, w + 36 * nd));
+    for (int nd = 0; nd < 10; nd++) l2[nd] = sigmoid(a1[nd]);
 #pragma unroll
     for (int nd = 0; nd < 10; nd++) l3[nd] = sigmoid(dot_w<10>(l2, w + 360 + 10 * nd));
 #pragma unroll
@@ -192,23 +226,31 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float* sd5, floa
 DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int bx, int by,
                            float n, float* t)
 {
-    const float three_n = 3.0f * n;
+    const Recip three_n = make_recip(3.0f * n), one_n = make_recip(n);
+    const Recip r49 = make_recip(49.0f), r9 = make_recip(9.0f);
     for (int e = threadIdx.x; e < FT * FT; e += blockDim.x) {
         int ty = e / FT, tx = e - ty * FT;
         int gy = clampi(by * TILE + ty - FH, H), gx = clampi(bx * TILE + tx - FH, W);
         size_t gi = (size_t)gy * W + gx;
         int o = ty * FT_PITCH + tx;
-        t[0 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_NORMAL * P, P, gi, three_n);
-        t[1 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_ALB1 * P, P, gi, three_n);
-        t[2 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_ALB2 * P, P, gi, three_n);
-        t[3 * FT * FT_PITCH + o] = primary3(planes + PTK_PL_WPOS * P, P, gi, three_n);
-        t[4 * FT * FT_PITCH + o] = planes[PTK_PL_DL * P + gi] / n;
+        float q[5];
+        q[0] = primary3(planes + PTK_PL_NORMAL * P, P, gi, three_n);
+        q[1] = primary3(planes + PTK_PL_ALB1 * P, P, gi, three_n);
+        q[2] = primary3(planes + PTK_PL_ALB2 * P, P, gi, three_n);
+        q[3] = primary3(planes + PTK_PL_WPOS * P, P, gi, three_n);
+        q[4] = div_by(planes[PTK_PL_DL * P + gi], one_n);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            t[k * FT * FT_PITCH + o] = q[k];
+            t[(5 + k) * FT * FT_PITCH + o] = div_by(q[k], r49);
+            t[(10 + k) * FT * FT_PITCH + o] = div_by(q[k], r9);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void features_mlp_kernel(DenoiseArgs a)
+__global__ __launch_bounds__(256, 4) void features_mlp_kernel(DenoiseArgs a)
 {
-    __shared__ float tile[5 * FT * FT_PITCH];
+    __shared__ float tile[15 * FT * FT_PITCH];
     const int W = a.width, H = a.height;
     const size_t P = (size_t)W * H;
     const float n = (float)a.sample_count;
@@ -219,18 +261,11 @@ __global__ __launch_bounds__(256) void features_mlp_kernel(DenoiseArgs a)
     const int x = blockIdx.x * TILE + lx, y = blockIdx.y * TILE + ly;
     if (x >= W || y >= H) return;
     const size_t idx = (size_t)y * W + x;
-    float sd5[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) sd5[k] = a.planes[(size_t)(PTK_PL_SD + 1 + k) * P + idx];
-    float f[36], var[7];
+    float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, f, var);
+    features_and_mlp(tile, ly, lx, a.planes, P, idx, 1.0f / n, w, a.features, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
-    if (a.features) {
-#pragma unroll
-        for (int k = 0; k < 36; k++) a.features[(size_t)k * P + idx] = f[k];
-    }
 }
 
 // ---- filter ---------------------------------------------------------------
@@ -242,13 +277,13 @@ DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int
 {
     const int S = TILE + 2 * N;
     const int SS = S * S;
-    const DivN dv = make_divn(nf);
+    const Recip dv = make_recip(nf);
     for (int e = threadIdx.x; e < SS; e += blockDim.x) {
         int ty = e / S, tx = e - ty * S;
         int gy = clampi(by * TILE + ty - N, H), gx = clampi(bx * TILE + tx - N, W);
         size_t gi = (size_t)gy * W + gx;
 #pragma unroll
-        for (int k = 0; k < 16; k++) t[k * SS + e] = dv(planes[(size_t)k * P + gi]);
+        for (int k = 0; k < 16; k++) t[k * SS + e] = div_by(planes[(size_t)k * P + gi], dv);
         t[16 * SS + e] = planes[(size_t)PTK_PL_SD * P + gi];
     }
 }
@@ -332,14 +367,14 @@ __global__ __launch_bounds__(256) void filter_kernel(DenoiseArgs a)
 }
 
 // ---- fused: features + MLP for the centre pixel, then the filter, one launch.
-__global__ __launch_bounds__(256) void denoise_fused_kernel(DenoiseArgs a)
+__global__ __launch_bounds__(256, 4) void denoise_fused_kernel(DenoiseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int W = a.width, H = a.height, N = a.n;
     const size_t P = (size_t)W * H;
     const int S = TILE + 2 * N;
     float* ptile = smem;
-    float* ftile = smem + 5 * FT * FT_PITCH;
+    float* ftile = smem + 15 * FT * FT_PITCH;
     const float n = (float)a.sample_count;
     load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, ptile);
     load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, n, ftile);
@@ -352,9 +387,9 @@ __global__ __launch_bounds__(256) void denoise_fused_kernel(DenoiseArgs a)
     float sd[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
-    float f[36], var[7];
+    float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    features_and_mlp(ptile, ly, lx, sd + 1, 1.0f / n, w, f, var);
+    features_and_mlp(ptile, ly, lx, a.planes, P, idx, 1.0f / n, w, nullptr, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
     float wsum[3], wc;
@@ -397,7 +432,7 @@ hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
 hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream)
 {
     dim3 grid((a.width + TILE - 1) / TILE, (a.height + TILE - 1) / TILE);
-    size_t lds = filter_lds_bytes(a.n) + 5 * FT * FT_PITCH * sizeof(float);
+    size_t lds = filter_lds_bytes(a.n) + 15 * FT * FT_PITCH * sizeof(float);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)denoise_fused_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

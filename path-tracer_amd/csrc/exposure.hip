@@ -2,7 +2,10 @@
 // (Renderers.cpp:1151-1159 and 1174-1193), and the stdDev refresh used after
 // a cross-GPU reduction.
 //
-// HBM-bound: 12 bytes read per pixel, one double atomic per workgroup.  Each
+// HBM-bound: 12 bytes read per pixel, one double atomic per workgroup.  The
+// atomics are spread over PTK_EXPOSURE_SHARDS partial sums, each on a cache
+// line of its own (same-address atomics retire one at a time, ~12 ns each, which
+// would cost more than the whole read); the host adds the shards in index order.  Each
 // lane reads float4 slices, evaluates the reference's fp32 per-pixel term and
 // sums in double; the wave reduces with DPP row operations.
 #include <hip/hip_runtime.h>
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(256) void exposure_kernel(const float* __restrict__
     if (lane == 0) wave_part[wave] = part;
     __syncthreads();
     if (threadIdx.x == 0)
-        atomicAdd(sum, (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]));
+        atomicAdd(sum + (blockIdx.x % PTK_EXPOSURE_SHARDS) * PTK_EXPOSURE_SHARD_STRIDE,
+                  (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]));
 }
 
 __global__ __launch_bounds__(256) void refresh_std_dev_kernel(float* __restrict__ planes, size_t P,

@@ -85,16 +85,16 @@ int bind(ptk_ctx* c)
 
 void free_image_buffers(ptk_ctx* c)
 {
-    hipFree(c->planes_d); c->planes_d = nullptr;
-    hipFree(c->seeds_d); c->seeds_d = nullptr;
-    if (c->seeds_h) hipHostFree(c->seeds_h);
+    (void)hipFree(c->planes_d); c->planes_d = nullptr;
+    (void)hipFree(c->seeds_d); c->seeds_d = nullptr;
+    if (c->seeds_h) (void)hipHostFree(c->seeds_h);
     c->seeds_h = nullptr;
     c->seed_capacity = 0;
-    hipFree(c->variances_d); c->variances_d = nullptr;
-    hipFree(c->features_d); c->features_d = nullptr;
-    hipFree(c->denoised_d); c->denoised_d = nullptr;
-    hipFree(c->wcsum_d); c->wcsum_d = nullptr;
-    if (c->staging_h) hipHostFree(c->staging_h);
+    (void)hipFree(c->variances_d); c->variances_d = nullptr;
+    (void)hipFree(c->features_d); c->features_d = nullptr;
+    (void)hipFree(c->denoised_d); c->denoised_d = nullptr;
+    (void)hipFree(c->wcsum_d); c->wcsum_d = nullptr;
+    if (c->staging_h) (void)hipHostFree(c->staging_h);
     c->staging_h = nullptr;
     c->staging_floats = 0;
 }
@@ -102,7 +102,7 @@ void free_image_buffers(ptk_ctx* c)
 int ensure_staging(ptk_ctx* c, size_t floats)
 {
     if (c->staging_floats >= floats) return PTK_OK;
-    if (c->staging_h) hipHostFree(c->staging_h);
+    if (c->staging_h) (void)hipHostFree(c->staging_h);
     c->staging_h = nullptr;
     c->staging_floats = 0;
     HIP_TRY(hipHostMalloc((void**)&c->staging_h, floats * sizeof(float), hipHostMallocDefault));
@@ -235,7 +235,7 @@ int ptk_create(int device, ptk_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev[1]);
     if (e == hipSuccess) e = hipMalloc((void**)&c->scene_d, sizeof(DevScene));
     if (e == hipSuccess) e = hipMalloc((void**)&c->rays_d, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->sum_d, sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->sum_d, PTK_EXPOSURE_SUM_DOUBLES * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&c->weights_d, 530 * sizeof(float));
     if (e != hipSuccess) {
         ptk_destroy(c);
@@ -248,16 +248,16 @@ int ptk_create(int device, ptk_ctx** out)
 int ptk_destroy(ptk_ctx* c)
 {
     if (!c) return PTK_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_image_buffers(c);
-    hipFree(c->scene_d);
-    hipFree(c->rays_d);
-    hipFree(c->sum_d);
-    hipFree(c->weights_d);
-    if (c->ev[0]) hipEventDestroy(c->ev[0]);
-    if (c->ev[1]) hipEventDestroy(c->ev[1]);
-    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipFree(c->scene_d);
+    (void)hipFree(c->rays_d);
+    (void)hipFree(c->sum_d);
+    (void)hipFree(c->weights_d);
+    if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
+    if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PTK_OK;
 }
@@ -368,8 +368,8 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
         if (want > (size_t)spp) want = (size_t)spp;
         if (want > c->seed_capacity) {
             HIP_TRY(hipStreamSynchronize(c->stream));
-            hipFree(c->seeds_d); c->seeds_d = nullptr;
-            if (c->seeds_h) hipHostFree(c->seeds_h);
+            (void)hipFree(c->seeds_d); c->seeds_d = nullptr;
+            if (c->seeds_h) (void)hipHostFree(c->seeds_h);
             c->seeds_h = nullptr;
             c->seed_capacity = 0;
             HIP_TRY(hipMalloc((void**)&c->seeds_d, want * per_pass));
@@ -522,14 +522,16 @@ int ptk_auto_exposure(ptk_ctx* c, int formula, float* exposure, double* raw_sum)
     if (formula < 0 || formula > 2) return fail(PTK_ERR_ARG, "ptk_auto_exposure: formula %d", formula);
     int rc = bind(c);
     if (rc != PTK_OK) return rc;
-    HIP_TRY(hipMemsetAsync(c->sum_d, 0, sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->sum_d, 0, PTK_EXPOSURE_SUM_DOUBLES * sizeof(double), c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     HIP_TRY(ptk_launch_exposure(c->planes_d, c->pixels, formula == 1 ? 1 : 0, c->sum_d, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    double sum = 0.0;
-    HIP_TRY(hipMemcpyAsync(&sum, c->sum_d, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    double shards[PTK_EXPOSURE_SUM_DOUBLES];
+    HIP_TRY(hipMemcpyAsync(shards, c->sum_d, sizeof shards, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->times.exposure_ms = elapsed_ms(c);
+    double sum = 0.0;
+    for (int i = 0; i < PTK_EXPOSURE_SHARDS; i++) sum += shards[i * PTK_EXPOSURE_SHARD_STRIDE];
     if (raw_sum) *raw_sum = sum;
     if (exposure) {
         const float n = (float)c->sample_count;

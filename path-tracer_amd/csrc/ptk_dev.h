@@ -62,7 +62,11 @@ hipError_t ptk_launch_render_exact(const RenderArgs& a, int max_depth, bool feat
 hipError_t ptk_launch_render_fast(const RenderArgs& a, int max_depth, bool features,
                                   hipStream_t stream);
 
-// Luminance map + sum of planes 0..2 into *sum_d (must be zero on entry).
+// Luminance map + sum of planes 0..2.  sum_d holds PTK_EXPOSURE_SHARDS partial sums
+// PTK_EXPOSURE_SHARD_STRIDE doubles apart (all zero on entry); the total is their sum.
+#define PTK_EXPOSURE_SHARDS 32
+#define PTK_EXPOSURE_SHARD_STRIDE 16
+#define PTK_EXPOSURE_SUM_DOUBLES (PTK_EXPOSURE_SHARDS * PTK_EXPOSURE_SHARD_STRIDE)
 hipError_t ptk_launch_exposure(const float* planes, size_t pixels, int formula, double* sum_d,
                                hipStream_t stream);
 
