@@ -1,11 +1,14 @@
 // denoise.hip -- denoiser inference: neighbourhood feature statistics + MLP
 // (DenoiserNN.cpp:12-301) and the cross-bilateral filter (Denoiser.cpp:222-355).
 //
-// Both passes are 16x16-output LDS-tiled stencils with clamp-to-edge halos.
-// Discrete parts (Sobel order, the "median getter" procedure, tie-breaking)
-// consume bit-exact primary features; the smooth parts (7x7 variance, mean
-// deviation, MLP, Gaussian weights) are evaluated in fp32 with FMA and the
-// hardware exp/log, and are compared with the reference within a tolerance.
+// Both passes are LDS-tiled stencils with clamp-to-edge halos.  A block of 256
+// threads produces a 32x8 tile of pixels; a wave covers two 32-pixel rows, so
+// the 32 lanes of a half-wave always read 32 consecutive LDS words (one bank
+// each) whatever the tap offset.  Discrete parts (Sobel order, the "median
+// getter" procedure, tie-breaking) consume bit-exact primary features; the
+// smooth parts (7x7 variance, mean deviation, MLP, Gaussian weights) are
+// evaluated in fp32 with FMA and the hardware exp/log, and are compared with
+// the reference within a tolerance.
 #include <hip/hip_runtime.h>
 
 #include "ptk_dev.h"
@@ -14,10 +17,14 @@
 
 namespace {
 
-constexpr int TILE = 16;
+#ifndef PTK_DN_WAVES
+#define PTK_DN_WAVES 3
+#endif
+constexpr int TW = 32, TH = 8;         // output tile
 constexpr int FH = 3;                  // feature halo (7x7 window)
-constexpr int FT = TILE + 2 * FH;      // 22
-constexpr int FT_PITCH = FT + 1;       // 23: odd pitch spreads rows over LDS banks
+constexpr int FW = TW + 2 * FH;        // 38
+constexpr int FR = TH + 2 * FH;        // 14
+constexpr int FPLANE = FW * FR;        // 532 words per feature plane
 
 DEV int clampi(int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); }
 
@@ -49,17 +56,19 @@ DEV float div_by(float x, const Recip& R)
 }
 
 // The reference's "median getter" procedure (DenoiserNN.cpp:190-256), literal,
-// on registers.  It is not a median.
+// on registers.  It is not a median.  In both passes the comparison with m[0]
+// has no effect (neither of its branches does anything for k == 0), so the
+// scan starts at k == 1.
 #pragma clang fp contract(off)
 DEV void mg_insert_pass1(float v, float (&m)[5])
 {
     bool done = false;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 1; k < 5; k++) {
         if (!done) {
             if (v > m[k]) {
                 if (k == 4) { float t = m[4]; m[3] = t; m[2] = t; m[1] = t; m[0] = t; m[4] = v; }
-            } else if (k > 0) {
+            } else {
                 m[k - 1] = v;
                 done = true;
             }
@@ -70,11 +79,11 @@ DEV void mg_insert_pass2(float v, float (&m)[5])
 {
     bool done = false;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 1; k < 5; k++) {
         if (!done) {
             if (v > m[k]) {
                 if (k == 4) { float t = m[4]; m[3] = t; m[2] = t; m[1] = t; m[0] = t; m[4] = v; }
-            } else if (k > 0) {
+            } else {
                 float t = m[k];
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -112,7 +121,7 @@ DEV float primary3(const float* __restrict__ p, size_t P, size_t i, const Recip&
 }
 #pragma clang fp contract(fast)
 
-// Weighted sum over `n` inputs with wave-uniform weights (scalar loads).
+// Weighted sum over N inputs with wave-uniform weights (scalar loads).
 template <int N>
 DEV float dot_w(const float (&x)[N], const __attribute__((address_space(4))) float* w)
 {
@@ -125,9 +134,15 @@ DEV float dot_w(const float (&x)[N], const __attribute__((address_space(4))) flo
 DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 
+// Device weight layout (built by the host from the reference's file order):
+//   [0, 350)   first layer, regrouped [channel k][group g][node]: w12[36*node + 5*g + k]
+//   [350, 360) first layer, input 35 (1/spp) per node
+//   [360, 460) second layer w23[10*node + input]
+//   [460, 530) third layer  w34[10*node + input]
+//
 // 36 features + MLP for the pixel at tile coordinates (ly, lx) of an LDS tile
-// `t` laid out [15][FT][FT_PITCH]: the primaries q, then q/49, then q/9 (the
-// terms the reference adds up for its 7x7 and 3x3 means, each rounded once).
+// `t` of 15 planes [FR][FW]: the primaries q, then q/49, then q/9 (the terms
+// the reference adds up for its 7x7 and 3x3 means, each rounded once).
 //
 // The five feature channels are processed one after another in a rolled loop
 // and each channel's seven features are folded into the ten first-layer sums
@@ -136,37 +151,36 @@ DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 // index order; the MLP is compared within a tolerance either way).
 // Feature index of group g (0 value, 1 sd, 2 mean7, 3 sd7, 4 gradient,
 // 5 mean deviation, 6 "MAD") and channel k is 5*g + k; index 35 is 1/spp.
-DEV void features_and_mlp(const float* t, int ly, int lx, const float* __restrict__ planes, size_t P,
-                          size_t idx, float inv_spp,
+DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5], float inv_spp,
                           const __attribute__((address_space(4))) float* w, float* features_out,
-                          float (&var)[7])
+                          size_t P, size_t idx, float (&var)[7])
 {
     float a1[10];
 #pragma unroll
-    for (int nd = 0; nd < 10; nd++) a1[nd] = inv_spp * w[36 * nd + 35];
+    for (int nd = 0; nd < 10; nd++) a1[nd] = inv_spp * w[350 + nd];
 
 #pragma unroll 1
     for (int k = 0; k < 5; k++) {
-        const float* tk = t + k * FT * FT_PITCH;
-        const float* tk49 = tk + 5 * FT * FT_PITCH;
-        const float* tk9 = tk + 10 * FT * FT_PITCH;
+        const float* tk = t + k * FPLANE + ly * FW + lx;   // window origin (top-left of 7x7)
+        const float* tk49 = tk + 5 * FPLANE;
+        const float* tk9 = tk + 10 * FPLANE;
         float fk[7];
-        fk[0] = tk[(ly + FH) * FT_PITCH + lx + FH];
-        fk[1] = planes[(size_t)(PTK_PL_SD + 1 + k) * P + idx];
+        fk[0] = tk[FH * FW + FH];
+        fk[1] = k == 0 ? sd5[0] : k == 1 ? sd5[1] : k == 2 ? sd5[2] : k == 3 ? sd5[3] : sd5[4];
 
         // 7x7 mean: the reference adds q/49 term by term in row-major order
         float mean7 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 7; j++)
 #pragma unroll
-            for (int i = 0; i < 7; i++) mean7 += tk49[(ly + j) * FT_PITCH + lx + i];
+            for (int i = 0; i < 7; i++) mean7 += tk49[j * FW + i];
         // 7x7 standard deviation about that mean
         float ss = 0.0f;
 #pragma unroll
         for (int j = 0; j < 7; j++)
 #pragma unroll
             for (int i = 0; i < 7; i++) {
-                float d = tk[(ly + j) * FT_PITCH + lx + i] - mean7;
+                float d = tk[j * FW + i] - mean7;
                 ss = __builtin_fmaf(d, d, ss);
             }
         fk[2] = mean7;
@@ -178,7 +192,7 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float* __restric
         for (int j = 0; j < 3; j++)
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                const int o = (ly + FH - 1 + j) * FT_PITCH + lx + FH - 1 + i;
+                const int o = (FH - 1 + j) * FW + FH - 1 + i;
                 win[j * 3 + i] = tk[o];
                 mean3 += tk9[o];
             }
@@ -200,12 +214,11 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float* __restric
         fk[5] = md;
         fk[6] = mad_procedure(win);
 
+        const auto* wk = w + 70 * k;
 #pragma unroll
-        for (int g = 0; g < 7; g++) {
-            const auto* wg = w + 5 * g + k;
+        for (int g = 0; g < 7; g++)
 #pragma unroll
-            for (int nd = 0; nd < 10; nd++) a1[nd] = __builtin_fmaf(fk[g], wg[36 * nd], a1[nd]);
-        }
+            for (int nd = 0; nd < 10; nd++) a1[nd] = __builtin_fmaf(fk[g], wk[10 * g + nd], a1[nd]);
         if (features_out) {
 #pragma unroll
             for (int g = 0; g < 7; g++) features_out[(size_t)(5 * g + k) * P + idx] = fk[g];
@@ -222,17 +235,17 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float* __restric
     for (int nd = 0; nd < 7; nd++) var[nd] = softplus(dot_w<10>(l3, w + 460 + 10 * nd));
 }
 
-// Loads the 22x22 tile of primaries around the block's 16x16 outputs.
+// Loads the (32+6)x(8+6) tile of primaries (and their /49, /9 images) around
+// the block's outputs.
 DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int bx, int by,
                            float n, float* t)
 {
     const Recip three_n = make_recip(3.0f * n), one_n = make_recip(n);
     const Recip r49 = make_recip(49.0f), r9 = make_recip(9.0f);
-    for (int e = threadIdx.x; e < FT * FT; e += blockDim.x) {
-        int ty = e / FT, tx = e - ty * FT;
-        int gy = clampi(by * TILE + ty - FH, H), gx = clampi(bx * TILE + tx - FH, W);
+    for (int e = threadIdx.x; e < FPLANE; e += 256) {
+        int ty = e / FW, tx = e - ty * FW;
+        int gy = clampi(by * TH + ty - FH, H), gx = clampi(bx * TW + tx - FH, W);
         size_t gi = (size_t)gy * W + gx;
-        int o = ty * FT_PITCH + tx;
         float q[5];
         q[0] = primary3(planes + PTK_PL_NORMAL * P, P, gi, three_n);
         q[1] = primary3(planes + PTK_PL_ALB1 * P, P, gi, three_n);
@@ -241,29 +254,35 @@ DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, in
         q[4] = div_by(planes[PTK_PL_DL * P + gi], one_n);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            t[k * FT * FT_PITCH + o] = q[k];
-            t[(5 + k) * FT * FT_PITCH + o] = div_by(q[k], r49);
-            t[(10 + k) * FT * FT_PITCH + o] = div_by(q[k], r9);
+            t[k * FPLANE + e] = q[k];
+            t[(5 + k) * FPLANE + e] = div_by(q[k], r49);
+            t[(10 + k) * FPLANE + e] = div_by(q[k], r9);
         }
     }
 }
 
-__global__ __launch_bounds__(256, 4) void features_mlp_kernel(DenoiseArgs a)
+__global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(DenoiseArgs a)
 {
-    __shared__ float tile[15 * FT * FT_PITCH];
+    __shared__ float tile[15 * FPLANE];
     const int W = a.width, H = a.height;
     const size_t P = (size_t)W * H;
     const float n = (float)a.sample_count;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = blockIdx.x * TW + lx, y = blockIdx.y * TH + ly;
+    const bool inside = x < W && y < H;
+    const size_t idx = inside ? (size_t)y * W + x : 0;
+    // issued before the tile load so their latency overlaps it
+    float sd5[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) sd5[k] = a.planes[(size_t)(PTK_PL_SD + 1 + k) * P + idx];
+
     load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, tile);
     __syncthreads();
+    if (!inside) return;
 
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = blockIdx.x * TILE + lx, y = blockIdx.y * TILE + ly;
-    if (x >= W || y >= H) return;
-    const size_t idx = (size_t)y * W + x;
     float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    features_and_mlp(tile, ly, lx, a.planes, P, idx, 1.0f / n, w, a.features, var);
+    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, a.features, P, idx, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
 }
@@ -275,12 +294,12 @@ constexpr int FV = 17;  // per tile element: col, normal, alb1, alb2, wpos (/n),
 DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int H, int bx, int by,
                           int N, float nf, float* t)
 {
-    const int S = TILE + 2 * N;
-    const int SS = S * S;
+    const int SW = TW + 2 * N, SH = TH + 2 * N;
+    const int SS = SW * SH;
     const Recip dv = make_recip(nf);
-    for (int e = threadIdx.x; e < SS; e += blockDim.x) {
-        int ty = e / S, tx = e - ty * S;
-        int gy = clampi(by * TILE + ty - N, H), gx = clampi(bx * TILE + tx - N, W);
+    for (int e = threadIdx.x; e < SS; e += 256) {
+        int ty = e / SW, tx = e - ty * SW;
+        int gy = clampi(by * TH + ty - N, H), gx = clampi(bx * TW + tx - N, W);
         size_t gi = (size_t)gy * W + gx;
 #pragma unroll
         for (int k = 0; k < 16; k++) t[k * SS + e] = div_by(planes[(size_t)k * P + gi], dv);
@@ -288,77 +307,103 @@ DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int
     }
 }
 
-// Filter taps for the pixel at tile coordinates (ly, lx); sd/var are the
-// centre pixel's.  Returns sum(w*col) and sum(w).
-DEV void filter_pixel(const float* t, int S, int ly, int lx, int N, const float* sd, const float* var,
-                      float (&wsum)[3], float& wc)
+struct FilterCoef {
+    float inv_idx, col_scale, sd0, inv_nrm, inv_a1, inv_a2, inv_wp, inv_dl;
+};
+DEV FilterCoef make_coef(const float* sd, const float* var)
 {
-    const int SS = S * S;
-    const int ce = (ly + N) * S + lx + N;
+    FilterCoef c;
+    c.sd0 = sd[0];
+    c.inv_idx = fast_rcp(2.0f * var[0]);
+    c.col_scale = 2.0f * var[1];
+    c.inv_nrm = fast_rcp(sd[1] * 2.0f * var[2] + 0.000001f);
+    c.inv_a1 = fast_rcp(sd[2] * 2.0f * var[3] + 0.000001f);
+    c.inv_a2 = fast_rcp(sd[3] * 2.0f * var[4] + 0.000001f);
+    c.inv_wp = fast_rcp(2.0f * sd[4] * var[5] + 0.000001f);
+    c.inv_dl = fast_rcp(sd[5] * 2.0f * var[6] + 0.000001f);
+    return c;
+}
+
+// One filter tap at tile word offset e (Denoiser.cpp:301-348): the product of
+// the seven Gaussians is one exp of the summed exponents.
+DEV void filter_tap(const float* t, int SS, int e, float dist_idx, const float (&pv)[16],
+                    const FilterCoef& c, float (&wsum)[3], float& wc)
+{
+    float q[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[k] = t[k * SS + e];
+    const float sd0q = t[16 * SS + e];
+    float d2[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float dx = q[3 * k] - pv[3 * k], dy = q[3 * k + 1] - pv[3 * k + 1],
+              dz = q[3 * k + 2] - pv[3 * k + 2];
+        d2[k] = dx * dx + dy * dy + dz * dz;
+    }
+    float ddl = q[15] - pv[15];
+    float arg = dist_idx * c.inv_idx;
+    arg += d2[0] * fast_rcp((c.sd0 + sd0q) * c.col_scale + 0.000001f);
+    arg += d2[1] * c.inv_nrm;
+    arg += d2[2] * c.inv_a1;
+    arg += d2[3] * c.inv_a2;
+    arg += d2[4] * c.inv_wp;
+    arg += ddl * ddl * c.inv_dl;
+    float w = fast_exp(-arg);
+    wsum[0] += q[0] * w;
+    wsum[1] += q[1] * w;
+    wsum[2] += q[2] * w;
+    wc += w;
+}
+
+// All taps of the pixel at tile coordinates (ly, lx).  NFIX > 0 unrolls the
+// (2N+1)^2 window at compile time.
+template <int NFIX>
+DEV void filter_pixel(const float* t, int SW, int SS, int ly, int lx, int N, const float* sd,
+                      const float* var, float (&wsum)[3], float& wc)
+{
+    const int ce = (ly + N) * SW + lx + N;
     float pv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) pv[k] = t[k * SS + ce];
-    const float sd0 = sd[0];
-    const float inv_idx = fast_rcp(2.0f * var[0]);
-    const float col_scale = 2.0f * var[1];
-    const float inv_nrm = fast_rcp(sd[1] * 2.0f * var[2] + 0.000001f);
-    const float inv_a1 = fast_rcp(sd[2] * 2.0f * var[3] + 0.000001f);
-    const float inv_a2 = fast_rcp(sd[3] * 2.0f * var[4] + 0.000001f);
-    const float inv_wp = fast_rcp(2.0f * sd[4] * var[5] + 0.000001f);
-    const float inv_dl = fast_rcp(sd[5] * 2.0f * var[6] + 0.000001f);
+    const FilterCoef c = make_coef(sd, var);
     wsum[0] = wsum[1] = wsum[2] = 0.0f;
     wc = 0.0f;
-    for (int j = -N; j <= N; j++) {
-        for (int i = -N; i <= N; i++) {
-            const int e = ce + j * S + i;
-            float q[16];
+    if (NFIX > 0) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) q[k] = t[k * SS + e];
-            const float sd0q = t[16 * SS + e];
-            float d2[5];
+        for (int j = -NFIX; j <= NFIX; j++)
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                float dx = q[3 * k] - pv[3 * k], dy = q[3 * k + 1] - pv[3 * k + 1],
-                      dz = q[3 * k + 2] - pv[3 * k + 2];
-                d2[k] = dx * dx + dy * dy + dz * dz;
-            }
-            float ddl = q[15] - pv[15];
-            float arg = (float)(j * j + i * i) * inv_idx;
-            arg += d2[0] * fast_rcp((sd0 + sd0q) * col_scale + 0.000001f);
-            arg += d2[1] * inv_nrm;
-            arg += d2[2] * inv_a1;
-            arg += d2[3] * inv_a2;
-            arg += d2[4] * inv_wp;
-            arg += ddl * ddl * inv_dl;
-            float w = fast_exp(-arg);
-            wsum[0] += q[0] * w;
-            wsum[1] += q[1] * w;
-            wsum[2] += q[2] * w;
-            wc += w;
-        }
+            for (int i = -NFIX; i <= NFIX; i++)
+                filter_tap(t, SS, ce + j * SW + i, (float)(j * j + i * i), pv, c, wsum, wc);
+    } else {
+        for (int j = -N; j <= N; j++)
+            for (int i = -N; i <= N; i++)
+                filter_tap(t, SS, ce + j * SW + i, (float)(j * j + i * i), pv, c, wsum, wc);
     }
 }
 
-__global__ __launch_bounds__(256) void filter_kernel(DenoiseArgs a)
+template <int NFIX>
+__global__ __launch_bounds__(256, PTK_DN_WAVES) void filter_kernel(DenoiseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float ftile[];
-    const int W = a.width, H = a.height, N = a.n;
+    const int W = a.width, H = a.height, N = NFIX > 0 ? NFIX : a.n;
     const size_t P = (size_t)W * H;
-    const int S = TILE + 2 * N;
-    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, (float)a.sample_count, ftile);
-    __syncthreads();
-
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = blockIdx.x * TILE + lx, y = blockIdx.y * TILE + ly;
-    if (x >= W || y >= H) return;
-    const size_t idx = (size_t)y * W + x;
+    const int SW = TW + 2 * N, SS = SW * (TH + 2 * N);
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = blockIdx.x * TW + lx, y = blockIdx.y * TH + ly;
+    const bool inside = x < W && y < H;
+    const size_t idx = inside ? (size_t)y * W + x : 0;
     float sd[6], var[7];
 #pragma unroll
     for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
 #pragma unroll
     for (int k = 0; k < 7; k++) var[k] = a.variances[(size_t)k * P + idx];
+
+    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, (float)a.sample_count, ftile);
+    __syncthreads();
+    if (!inside) return;
+
     float wsum[3], wc;
-    filter_pixel(ftile, S, ly, lx, N, sd, var, wsum, wc);
+    filter_pixel<NFIX>(ftile, SW, SS, ly, lx, N, sd, var, wsum, wc);
     const float inv = 1.0f / wc;
     a.denoised[idx] = wsum[0] * inv;
     a.denoised[P + idx] = wsum[1] * inv;
@@ -367,33 +412,37 @@ __global__ __launch_bounds__(256) void filter_kernel(DenoiseArgs a)
 }
 
 // ---- fused: features + MLP for the centre pixel, then the filter, one launch.
-__global__ __launch_bounds__(256, 4) void denoise_fused_kernel(DenoiseArgs a)
+template <int NFIX>
+__global__ __launch_bounds__(256, PTK_DN_WAVES) void denoise_fused_kernel(DenoiseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int W = a.width, H = a.height, N = a.n;
+    const int W = a.width, H = a.height, N = NFIX > 0 ? NFIX : a.n;
     const size_t P = (size_t)W * H;
-    const int S = TILE + 2 * N;
+    const int SW = TW + 2 * N, SS = SW * (TH + 2 * N);
     float* ptile = smem;
-    float* ftile = smem + 15 * FT * FT_PITCH;
+    float* ftile = smem + 15 * FPLANE;
     const float n = (float)a.sample_count;
-    load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, ptile);
-    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, n, ftile);
-    __syncthreads();
-
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = blockIdx.x * TILE + lx, y = blockIdx.y * TILE + ly;
-    if (x >= W || y >= H) return;
-    const size_t idx = (size_t)y * W + x;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = blockIdx.x * TW + lx, y = blockIdx.y * TH + ly;
+    const bool inside = x < W && y < H;
+    const size_t idx = inside ? (size_t)y * W + x : 0;
     float sd[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
+
+    load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, ptile);
+    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, n, ftile);
+    __syncthreads();
+    if (!inside) return;
+
     float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    features_and_mlp(ptile, ly, lx, a.planes, P, idx, 1.0f / n, w, nullptr, var);
+    const float sd5[5] = {sd[1], sd[2], sd[3], sd[4], sd[5]};
+    features_and_mlp(ptile, ly, lx, sd5, 1.0f / n, w, nullptr, P, idx, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
     float wsum[3], wc;
-    filter_pixel(ftile, S, ly, lx, N, sd, var, wsum, wc);
+    filter_pixel<NFIX>(ftile, SW, SS, ly, lx, N, sd, var, wsum, wc);
     const float inv = 1.0f / wc;
     a.denoised[idx] = wsum[0] * inv;
     a.denoised[P + idx] = wsum[1] * inv;
@@ -403,41 +452,42 @@ __global__ __launch_bounds__(256, 4) void denoise_fused_kernel(DenoiseArgs a)
 
 size_t filter_lds_bytes(int N)
 {
-    size_t S = TILE + 2 * (size_t)N;
-    return S * S * FV * sizeof(float);
+    size_t sw = TW + 2 * (size_t)N, sh = TH + 2 * (size_t)N;
+    return sw * sh * FV * sizeof(float);
+}
+
+template <class K>
+hipError_t launch_dyn(K kernel, const DenoiseArgs& a, size_t lds, hipStream_t stream)
+{
+    dim3 grid((a.width + TW - 1) / TW, (a.height + TH - 1) / TH);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
 {
-    dim3 grid((a.width + TILE - 1) / TILE, (a.height + TILE - 1) / TILE);
+    dim3 grid((a.width + TW - 1) / TW, (a.height + TH - 1) / TH);
     hipLaunchKernelGGL(features_mlp_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
 {
-    dim3 grid((a.width + TILE - 1) / TILE, (a.height + TILE - 1) / TILE);
     size_t lds = filter_lds_bytes(a.n);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)filter_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(filter_kernel, grid, dim3(256), lds, stream, a);
-    return hipGetLastError();
+    if (a.n == 1) return launch_dyn(filter_kernel<1>, a, lds, stream);
+    return launch_dyn(filter_kernel<0>, a, lds, stream);
 }
 
 hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream)
 {
-    dim3 grid((a.width + TILE - 1) / TILE, (a.height + TILE - 1) / TILE);
-    size_t lds = filter_lds_bytes(a.n) + 15 * FT * FT_PITCH * sizeof(float);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)denoise_fused_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(denoise_fused_kernel, grid, dim3(256), lds, stream, a);
-    return hipGetLastError();
+    size_t lds = filter_lds_bytes(a.n) + 15 * FPLANE * sizeof(float);
+    if (a.n == 1) return launch_dyn(denoise_fused_kernel<1>, a, lds, stream);
+    return launch_dyn(denoise_fused_kernel<0>, a, lds, stream);
 }

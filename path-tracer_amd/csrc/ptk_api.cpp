@@ -560,8 +560,14 @@ int ptk_denoise(ptk_ctx* c, const float* w12, const float* w23, const float* w34
     int rc = bind(c);
     if (rc != PTK_OK) return rc;
     const size_t P = c->pixels;
+    // device layout: first layer regrouped [channel][feature group][node] so the
+    // kernel's per-channel weights are 70 consecutive floats, then the 1/spp
+    // column, then layers two and three in file order
     float w[530];
-    std::memcpy(w, w12, 360 * sizeof(float));
+    for (int k = 0; k < 5; k++)
+        for (int g = 0; g < 7; g++)
+            for (int nd = 0; nd < 10; nd++) w[70 * k + 10 * g + nd] = w12[36 * nd + 5 * g + k];
+    for (int nd = 0; nd < 10; nd++) w[350 + nd] = w12[36 * nd + 35];
     std::memcpy(w + 360, w23, 100 * sizeof(float));
     std::memcpy(w + 460, w34, 70 * sizeof(float));
     HIP_TRY(hipMemcpyAsync(c->weights_d, w, sizeof w, hipMemcpyHostToDevice, c->stream));
