@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--math", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo rehearses the multi-rank path with several ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denoise-probe", action="store_true")
     args = ap.parse_args()
@@ -126,14 +128,18 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libptk has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    device = torch.device("cuda", gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, H = args.width, args.height
-    ctx = ptk.Context(local_rank)
+    ctx = ptk.Context(gpu)
     raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", args.scene + ".scene"),
                                     W, H, args.depth, 0.005, False)
     ctx.set_constants(raw)
@@ -151,13 +157,16 @@ def main():
         if world > 1:
             # per-frame accumulation exchange: sum of the colour planes over ranks
             frame.copy_(planes[0:3])
-            dist.all_reduce(frame)
+            # the next render (on the context's own stream) rewrites these planes: let the
+            # snapshot finish first; the all-reduce itself overlaps the next step
+            torch.cuda.current_stream(device).synchronize()
+            multigpu.all_reduce_(frame)
 
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[gpu]) if args.backend == "nccl" else dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -171,7 +180,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        multigpu.all_reduce_(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     samples_total = float(W) * H * spp * args.steps * world
@@ -217,7 +226,7 @@ def main():
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[gpu]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

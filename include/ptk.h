@@ -188,6 +188,20 @@ int ptk_denoise(ptk_ctx* ctx, const float w12[360], const float w23[100], const 
                 int n, int variant, float* denoised_3p, float* wc_sum_p, float* variances_7p,
                 float* features_36p);
 
+/* Row-band form of ptk_denoise for sharding the denoiser across GPUs: produces
+ * rows [row_begin, row_end) only and leaves the results in device memory
+ * (plane-major: 3 colour planes, 1 weight-sum plane, 7 bandwidth planes; see
+ * ptk_denoise_outputs_device).  Reads the accumulator planes of up to
+ * max(3, n) rows on either side of the band, which must therefore be valid on
+ * this GPU.  The reference has no counterpart (its denoiser is single-GPU,
+ * Denoiser.cpp:3-38). */
+int ptk_denoise_rows(ptk_ctx* ctx, const float w12[360], const float w23[100],
+                     const float w34[70], int n, int variant, int row_begin, int row_end);
+
+/* Device addresses of the denoiser outputs (any pointer may be null). */
+int ptk_denoise_outputs_device(ptk_ctx* ctx, float** denoised_d, float** wc_sum_d,
+                               float** variances_d);
+
 /* Replaces the chrono globals; see ptk_times. */
 int ptk_timing(ptk_ctx* ctx, ptk_times* out);
 

@@ -237,14 +237,14 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
 
 // Loads the (32+6)x(8+6) tile of primaries (and their /49, /9 images) around
 // the block's outputs.
-DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int bx, int by,
+DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int x0, int y0,
                            float n, float* t)
 {
     const Recip three_n = make_recip(3.0f * n), one_n = make_recip(n);
     const Recip r49 = make_recip(49.0f), r9 = make_recip(9.0f);
     for (int e = threadIdx.x; e < FPLANE; e += 256) {
         int ty = e / FW, tx = e - ty * FW;
-        int gy = clampi(by * TH + ty - FH, H), gx = clampi(bx * TW + tx - FH, W);
+        int gy = clampi(y0 + ty - FH, H), gx = clampi(x0 + tx - FH, W);
         size_t gi = (size_t)gy * W + gx;
         float q[5];
         q[0] = primary3(planes + PTK_PL_NORMAL * P, P, gi, three_n);
@@ -268,15 +268,16 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
     const size_t P = (size_t)W * H;
     const float n = (float)a.sample_count;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = blockIdx.x * TW + lx, y = blockIdx.y * TH + ly;
-    const bool inside = x < W && y < H;
+    const int x0 = blockIdx.x * TW, y0 = a.row_begin + blockIdx.y * TH;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = x < W && y < a.row_end;
     const size_t idx = inside ? (size_t)y * W + x : 0;
     // issued before the tile load so their latency overlaps it
     float sd5[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) sd5[k] = a.planes[(size_t)(PTK_PL_SD + 1 + k) * P + idx];
 
-    load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, tile);
+    load_primary_tile(a.planes, P, W, H, x0, y0, n, tile);
     __syncthreads();
     if (!inside) return;
 
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
 
 constexpr int FV = 17;  // per tile element: col, normal, alb1, alb2, wpos (/n), dl/n, sd0
 
-DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int H, int bx, int by,
+DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int H, int x0, int y0,
                           int N, float nf, float* t)
 {
     const int SW = TW + 2 * N, SH = TH + 2 * N;
@@ -299,7 +300,7 @@ DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int
     const Recip dv = make_recip(nf);
     for (int e = threadIdx.x; e < SS; e += 256) {
         int ty = e / SW, tx = e - ty * SW;
-        int gy = clampi(by * TH + ty - N, H), gx = clampi(bx * TW + tx - N, W);
+        int gy = clampi(y0 + ty - N, H), gx = clampi(x0 + tx - N, W);
         size_t gi = (size_t)gy * W + gx;
 #pragma unroll
         for (int k = 0; k < 16; k++) t[k * SS + e] = div_by(planes[(size_t)k * P + gi], dv);
@@ -389,8 +390,9 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void filter_kernel(DenoiseArgs a
     const size_t P = (size_t)W * H;
     const int SW = TW + 2 * N, SS = SW * (TH + 2 * N);
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = blockIdx.x * TW + lx, y = blockIdx.y * TH + ly;
-    const bool inside = x < W && y < H;
+    const int x0 = blockIdx.x * TW, y0 = a.row_begin + blockIdx.y * TH;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = x < W && y < a.row_end;
     const size_t idx = inside ? (size_t)y * W + x : 0;
     float sd[6], var[7];
 #pragma unroll
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void filter_kernel(DenoiseArgs a
 #pragma unroll
     for (int k = 0; k < 7; k++) var[k] = a.variances[(size_t)k * P + idx];
 
-    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, (float)a.sample_count, ftile);
+    load_filter_tile(a.planes, P, W, H, x0, y0, N, (float)a.sample_count, ftile);
     __syncthreads();
     if (!inside) return;
 
@@ -423,15 +425,16 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void denoise_fused_kernel(Denois
     float* ftile = smem + 15 * FPLANE;
     const float n = (float)a.sample_count;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = blockIdx.x * TW + lx, y = blockIdx.y * TH + ly;
-    const bool inside = x < W && y < H;
+    const int x0 = blockIdx.x * TW, y0 = a.row_begin + blockIdx.y * TH;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = x < W && y < a.row_end;
     const size_t idx = inside ? (size_t)y * W + x : 0;
     float sd[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
 
-    load_primary_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, n, ptile);
-    load_filter_tile(a.planes, P, W, H, blockIdx.x, blockIdx.y, N, n, ftile);
+    load_primary_tile(a.planes, P, W, H, x0, y0, n, ptile);
+    load_filter_tile(a.planes, P, W, H, x0, y0, N, n, ftile);
     __syncthreads();
     if (!inside) return;
 
@@ -459,7 +462,7 @@ size_t filter_lds_bytes(int N)
 template <class K>
 hipError_t launch_dyn(K kernel, const DenoiseArgs& a, size_t lds, hipStream_t stream)
 {
-    dim3 grid((a.width + TW - 1) / TW, (a.height + TH - 1) / TH);
+    dim3 grid((a.width + TW - 1) / TW, (a.row_end - a.row_begin + TH - 1) / TH);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -473,7 +476,7 @@ hipError_t launch_dyn(K kernel, const DenoiseArgs& a, size_t lds, hipStream_t st
 
 hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
 {
-    dim3 grid((a.width + TW - 1) / TW, (a.height + TH - 1) / TH);
+    dim3 grid((a.width + TW - 1) / TW, (a.row_end - a.row_begin + TH - 1) / TH);
     hipLaunchKernelGGL(features_mlp_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -547,16 +547,22 @@ int ptk_auto_exposure(ptk_ctx* c, int formula, float* exposure, double* raw_sum)
     return PTK_OK;
 }
 
-int ptk_denoise(ptk_ctx* c, const float* w12, const float* w23, const float* w34, int n,
-                int variant, float* denoised, float* wc_sum, float* variances, float* features)
+namespace {
+// Uploads the weights and runs the denoiser on rows [row_begin, row_end); the
+// results stay in the context's device planes.
+int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* w34, int n,
+                   int variant, int row_begin, int row_end, bool want_features)
 {
     if (!c || !w12 || !w23 || !w34) return fail(PTK_ERR_ARG, "ptk_denoise: null argument");
     if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_denoise before ptk_set_constants");
     if (c->sample_count < 1) return fail(PTK_ERR_STATE, "ptk_denoise: no samples accumulated");
     if (n < 0 || n > 8) return fail(PTK_ERR_ARG, "ptk_denoise: N %d outside [0,8]", n);
     if (variant != 0 && variant != 1) return fail(PTK_ERR_ARG, "ptk_denoise: variant %d", variant);
-    if (variant == 1 && features)
+    if (variant == 1 && want_features)
         return fail(PTK_ERR_ARG, "ptk_denoise: the fused variant does not materialise features");
+    if (row_begin < 0 || row_end > c->height || row_begin > row_end)
+        return fail(PTK_ERR_ARG, "ptk_denoise: rows [%d,%d) outside [0,%d)", row_begin, row_end,
+                    c->height);
     int rc = bind(c);
     if (rc != PTK_OK) return rc;
     const size_t P = c->pixels;
@@ -572,19 +578,23 @@ int ptk_denoise(ptk_ctx* c, const float* w12, const float* w23, const float* w34
     std::memcpy(w + 460, w34, 70 * sizeof(float));
     HIP_TRY(hipMemcpyAsync(c->weights_d, w, sizeof w, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // w is on this frame's stack
-    if (features && !c->features_d) HIP_TRY(hipMalloc((void**)&c->features_d, 36 * P * sizeof(float)));
+    if (want_features && !c->features_d)
+        HIP_TRY(hipMalloc((void**)&c->features_d, 36 * P * sizeof(float)));
 
     DenoiseArgs a;
     a.planes = c->planes_d;
     a.weights = c->weights_d;
     a.variances = c->variances_d;
-    a.features = features ? c->features_d : nullptr;
+    a.features = want_features ? c->features_d : nullptr;
     a.denoised = c->denoised_d;
     a.wc_sum = c->wcsum_d;
     a.width = c->width;
     a.height = c->height;
     a.sample_count = c->sample_count;
     a.n = n;
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    if (row_begin == row_end) return PTK_OK;
     if (variant == 0) {
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         HIP_TRY(ptk_launch_features_mlp(a, c->stream));
@@ -603,7 +613,16 @@ int ptk_denoise(ptk_ctx* c, const float* w12, const float* w23, const float* w34
         c->times.features_ms = 0.0;
         c->times.filter_ms = 0.0;
     }
+    return PTK_OK;
+}
+}  // namespace
 
+int ptk_denoise(ptk_ctx* c, const float* w12, const float* w23, const float* w34, int n,
+                int variant, float* denoised, float* wc_sum, float* variances, float* features)
+{
+    int rc = denoise_device(c, w12, w23, w34, n, variant, 0, c ? c->height : 0, features != nullptr);
+    if (rc != PTK_OK) return rc;
+    const size_t P = c->pixels;
     struct { float* dst; const float* src; int n; } jobs[] = {
         {denoised, c->denoised_d, 3}, {wc_sum, c->wcsum_d, 1},
         {variances, c->variances_d, 7}, {features, c->features_d, 36},
@@ -618,6 +637,25 @@ int ptk_denoise(ptk_ctx* c, const float* w12, const float* w23, const float* w34
             for (int k = 0; k < j.n; k++) j.dst[i * j.n + k] = c->staging_h[(size_t)k * P + i];
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_denoise_rows(ptk_ctx* c, const float* w12, const float* w23, const float* w34, int n,
+                     int variant, int row_begin, int row_end)
+{
+    int rc = denoise_device(c, w12, w23, w34, n, variant, row_begin, row_end, false);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_denoise_outputs_device(ptk_ctx* c, float** denoised_d, float** wc_sum_d, float** variances_d)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_denoise_outputs_device: null context");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_denoise_outputs_device before ptk_set_constants");
+    if (denoised_d) *denoised_d = c->denoised_d;
+    if (wc_sum_d) *wc_sum_d = c->wcsum_d;
+    if (variances_d) *variances_d = c->variances_d;
     return PTK_OK;
 }
 

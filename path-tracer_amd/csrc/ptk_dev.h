@@ -84,6 +84,7 @@ struct DenoiseArgs {
     int32_t width, height;
     int32_t sample_count;
     int32_t n;              // filter half-width
+    int32_t row_begin, row_end;  // rows [row_begin, row_end) are produced (a band, or the image)
 };
 hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream);
 hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream);

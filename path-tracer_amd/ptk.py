@@ -24,7 +24,7 @@ EXPORTS = [
     "ptk_set_math_mode", "ptk_set_stream_id", "ptk_render", "ptk_read_accumulators",
     "ptk_read_planes", "ptk_write_planes", "ptk_planes_device", "ptk_get_sample_count",
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
-    "ptk_timing", "ptk_synchronize",
+    "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_timing", "ptk_synchronize",
 ]
 
 
@@ -69,6 +69,8 @@ def load():
     L.ptk_refresh_std_dev.argtypes = [vp]
     L.ptk_auto_exposure.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_double)]
     L.ptk_denoise.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]
+    L.ptk_denoise_rows.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ptk_denoise_outputs_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
     for name in EXPORTS:
@@ -207,6 +209,19 @@ class Context:
                                         _fp(res["denoised"]), _fp(res["wcSum"]),
                                         _fp(res["variances"]), _fp(res["features"])))
         return res
+
+    def denoise_rows(self, weights, n, variant, row_begin, row_end):
+        """Denoises rows [row_begin, row_end); results stay on the device."""
+        w12, w23, w34 = (np.ascontiguousarray(w, dtype=np.float32) for w in weights)
+        self._check(self._L.ptk_denoise_rows(self._h, _fp(w12), _fp(w23), _fp(w34), n, variant,
+                                             row_begin, row_end))
+
+    def denoise_outputs_device(self):
+        """Device addresses (denoised 3 planes, wcSum 1 plane, variances 7 planes)."""
+        d, w, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._L.ptk_denoise_outputs_device(self._h, C.byref(d), C.byref(w),
+                                                       C.byref(v)))
+        return int(d.value), int(w.value), int(v.value)
 
     def timing(self):
         t = Times()

@@ -262,3 +262,31 @@ def test_counter_seeded_image_converges_to_the_reference_seeded_one(ctx, oracle)
     spread = np.sqrt(np.nanmean(orc ** 2))
     assert noise < 0.02 * spread      # matched seeds: only a few diverged paths
     assert rmse < 1.0 * spread        # independent seeds at 64 spp: bounded by the estimator noise
+
+
+def test_denoise_row_bands_tile_the_full_result(ctx, oracle):
+    """Bands of any height (not tile aligned) reproduce the whole-image denoise bit for bit."""
+    import ptk
+    import torch
+    import multigpu
+    O = oracle
+    W, H = 157, 83
+    sc = O.load_scene(scene_path("MultiLightGlass"))
+    ctx.set_constants(O.build_constants(sc, W, H, 4, 0.005, True))
+    w = O.load_weights(weights_path("BEST"))
+    ctx.render(16, ptk.SEED_COUNTER)
+    for variant in (0, 1):
+        full = ctx.denoise(w, 2, variant)
+        den, wc = multigpu.device_denoised(ctx, torch.device("cuda", 0))
+        den.zero_()
+        wc.zero_()
+        torch.cuda.synchronize()
+        for y0, y1 in ((0, 5), (5, 5), (5, 41), (41, 82), (82, 83)):
+            ctx.denoise_rows(w, 2, variant, y0, y1)
+        got = den.cpu().numpy().T
+        assert np.array_equal(got, full["denoised"], equal_nan=True)
+        assert np.array_equal(wc.cpu().numpy(), full["wcSum"].reshape(-1), equal_nan=True)
+    with pytest.raises(ptk.PtkError):
+        ctx.denoise_rows(w, 1, 0, 10, 5)
+    with pytest.raises(ptk.PtkError):
+        ctx.denoise_rows(w, 1, 0, 0, H + 1)
