@@ -349,6 +349,9 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     a.stream_id = c->stream_id;
     a.width = c->width;
     a.height = c->height;
+    a.has_blur = 0;
+    for (int i = 0; i < c->host_scene.num_shapes; i++)
+        if (c->host_scene.mats[c->host_scene.shape[i].mat][3] > 0.0f) a.has_blur = 1;
     auto launch = c->math_mode == PTK_MATH_FAST ? ptk_launch_render_fast : ptk_launch_render_exact;
 
     double render_ms = 0.0, seed_ms = 0.0;

@@ -53,6 +53,7 @@ struct RenderArgs {
     int32_t width, height;
     int32_t spp;             // passes in this launch
     int32_t base_count;      // sampleCount before this launch
+    int32_t has_blur;        // some shape's material has blur > 0
 };
 
 // Launchers (defined next to their kernels).  All enqueue on `stream` and
