@@ -261,6 +261,33 @@ DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, in
     }
 }
 
+// Tile of this workgroup.  Workgroups are dealt to the eight XCDs round-robin in
+// launch order and each XCD has its own L2, so with the natural numbering the
+// eight neighbours of a tile sit on eight different L2s and every halo element
+// is fetched across the fabric once per tile.  Here workgroup b takes tile
+// (b % 8) * ceil(tiles / 8) + b / 8: each XCD works through one contiguous run
+// of tile rows, and the halo re-reads hit its own L2.  The grid is padded to a
+// multiple of eight; padding workgroups own no tile.
+#ifndef PTK_DN_XCD_REMAP
+#define PTK_DN_XCD_REMAP 1
+#endif
+DEV int tiles_x(const DenoiseArgs& a) { return (a.width + TW - 1) / TW; }
+DEV int tiles_y(const DenoiseArgs& a) { return (a.row_end - a.row_begin + TH - 1) / TH; }
+DEV bool tile_origin(const DenoiseArgs& a, int& x0, int& y0)
+{
+    const int nbx = tiles_x(a), nb = nbx * tiles_y(a);
+#if PTK_DN_XCD_REMAP
+    const int per = (nb + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+#else
+    const int t = blockIdx.x;
+#endif
+    if (t >= nb) return false;
+    x0 = (t % nbx) * TW;
+    y0 = a.row_begin + (t / nbx) * TH;
+    return true;
+}
+
 __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(DenoiseArgs a)
 {
     __shared__ float tile[15 * FPLANE];
@@ -268,7 +295,8 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
     const size_t P = (size_t)W * H;
     const float n = (float)a.sample_count;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x0 = blockIdx.x * TW, y0 = a.row_begin + blockIdx.y * TH;
+    int x0, y0;
+    if (!tile_origin(a, x0, y0)) return;   // uniform over the workgroup, before any barrier
     const int x = x0 + lx, y = y0 + ly;
     const bool inside = x < W && y < a.row_end;
     const size_t idx = inside ? (size_t)y * W + x : 0;
@@ -390,7 +418,8 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void filter_kernel(DenoiseArgs a
     const size_t P = (size_t)W * H;
     const int SW = TW + 2 * N, SS = SW * (TH + 2 * N);
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x0 = blockIdx.x * TW, y0 = a.row_begin + blockIdx.y * TH;
+    int x0, y0;
+    if (!tile_origin(a, x0, y0)) return;   // uniform over the workgroup, before any barrier
     const int x = x0 + lx, y = y0 + ly;
     const bool inside = x < W && y < a.row_end;
     const size_t idx = inside ? (size_t)y * W + x : 0;
@@ -425,7 +454,8 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void denoise_fused_kernel(Denois
     float* ftile = smem + 15 * FPLANE;
     const float n = (float)a.sample_count;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x0 = blockIdx.x * TW, y0 = a.row_begin + blockIdx.y * TH;
+    int x0, y0;
+    if (!tile_origin(a, x0, y0)) return;   // uniform over the workgroup, before any barrier
     const int x = x0 + lx, y = y0 + ly;
     const bool inside = x < W && y < a.row_end;
     const size_t idx = inside ? (size_t)y * W + x : 0;
@@ -459,10 +489,17 @@ size_t filter_lds_bytes(int N)
     return sw * sh * FV * sizeof(float);
 }
 
+unsigned denoise_grid(const DenoiseArgs& a)
+{
+    const unsigned nb = (unsigned)((a.width + TW - 1) / TW) *
+                        (unsigned)((a.row_end - a.row_begin + TH - 1) / TH);
+    return (nb + 7u) / 8u * 8u;
+}
+
 template <class K>
 hipError_t launch_dyn(K kernel, const DenoiseArgs& a, size_t lds, hipStream_t stream)
 {
-    dim3 grid((a.width + TW - 1) / TW, (a.row_end - a.row_begin + TH - 1) / TH);
+    dim3 grid(denoise_grid(a));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -476,7 +513,7 @@ hipError_t launch_dyn(K kernel, const DenoiseArgs& a, size_t lds, hipStream_t st
 
 hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
 {
-    dim3 grid((a.width + TW - 1) / TW, (a.row_end - a.row_begin + TH - 1) / TH);
+    dim3 grid(denoise_grid(a));
     hipLaunchKernelGGL(features_mlp_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
