@@ -29,6 +29,8 @@ import ptk  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector fp32 peak (FMA = 2 flop)
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
+PEAK_VALU_ISSUE_T = 78.6   # lane-instructions/s: 256 CUs x 4 SIMDs x 32 lanes/cycle x 2.4 GHz
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r01_profile_summary.json")
 
 
 def load_opcount(scene):
@@ -38,6 +40,21 @@ def load_opcount(scene):
     with open(path) as f:
         table = json.load(f)
     return table[scene]
+
+
+def load_profile(samples_per_launch, features):
+    """Per-launch PMC figures of the render kernel from the committed rocprofv3 passes
+    (scripts/collect_profiles.sh), valid only for the launch size they were taken at."""
+    try:
+        with open(PROFILE_SUMMARY) as f:
+            doc = json.load(f)
+        if doc["bench"]["config"]["samples_per_step_per_gpu"] != samples_per_launch:
+            return None
+        want = "render_kernel<4, %s," % ("true" if features else "false")
+        k = next(v for name, v in doc["kernels"].items() if name.startswith(want))
+        return k
+    except (OSError, KeyError, StopIteration, ValueError):
+        return None
 
 
 def cpu_baseline(scene, W, H, depth):
@@ -211,9 +228,33 @@ def main():
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": None, "avg_launch_ms": avg_ms,
                 "flops_per_sample": flops, "int_ops_per_sample": ops.get("int_ops_per_sample"),
+                "algorithmic_bytes": 2 * 3 * 4 * W * H,   # colour planes read + written once
                 "note": "fp32 VALU bound (not HBM, not MFMA): algorithmic flops per sample from "
-                        "the op-counting build of the CPU restatement",
+                        "the op-counting build of the CPU restatement; a correctly rounded "
+                        "divide / sqrt / sin counts as one flop and no operation may be fused, so "
+                        "the FMA peak is an upper bound no exact-arithmetic kernel can approach",
             }
+            prof = load_profile(int(samples_per_launch), False) if args.scene == "cornell_crystal" \
+                else None
+            if prof and "pmc_per_launch" in prof:
+                pmc = prof["pmc_per_launch"]
+                if "hbm_read_bytes_per_launch" in prof:
+                    out["roofline"]["traffic"] = (prof["hbm_read_bytes_per_launch"]
+                                                  + prof["hbm_write_bytes_per_launch"])
+                    out["roofline"]["traffic_note"] = (
+                        "rocprofv3 FETCH_SIZE (x calibration) + WRITE_SIZE per launch from "
+                        "profiles/r01_profile_summary.json: register-spill scratch traffic, "
+                        "not plane traffic")
+                if "SQ_INSTS_VALU" in pmc:
+                    lane_instr = pmc["SQ_INSTS_VALU"] * 64.0
+                    rate = lane_instr / (avg_ms * 1e-3) / 1e12
+                    out["roofline"]["valu_issue"] = {
+                        "lane_instructions_per_sample": lane_instr / samples_per_launch,
+                        "achieved": rate, "peak": PEAK_VALU_ISSUE_T, "unit": "T lane-instr/s",
+                        "frac": rate / PEAK_VALU_ISSUE_T,
+                        "active_lane_frac": pmc.get("SQ_THREAD_CYCLES_VALU", 0.0)
+                        / pmc["SQ_INSTS_VALU"] / 64.0,
+                    }
         except (OSError, KeyError) as exc:
             out["roofline"] = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_TFLOPS,
                                "unit": "TFLOP/s", "frac": None, "traffic": None,

@@ -18,6 +18,13 @@ def short(name):
 
 def main(out_dir):
     doc = {"kernels": {}}
+    try:
+        with open(os.path.join(out_dir, "bench_under_rocprof.json")) as f:
+            bench = json.loads(f.read().strip().splitlines()[-1])
+        doc["bench"] = {k: bench[k] for k in ("metric", "value", "unit", "ms_per_step", "config")}
+        doc["bench"]["roofline_avg_launch_ms"] = bench["roofline"]["avg_launch_ms"]
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
     for f in glob.glob(os.path.join(out_dir, "kt", "**", "*kernel_trace.csv"), recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
