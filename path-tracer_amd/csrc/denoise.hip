@@ -17,8 +17,15 @@
 
 namespace {
 
+// waves per SIMD the register allocation is capped for, per kernel
 #ifndef PTK_DN_WAVES
 #define PTK_DN_WAVES 3
+#endif
+#ifndef PTK_DN_WAVES_FILTER
+#define PTK_DN_WAVES_FILTER 3
+#endif
+#ifndef PTK_DN_WAVES_FUSED
+#define PTK_DN_WAVES_FUSED 3
 #endif
 constexpr int TW = 32, TH = 8;         // output tile
 constexpr int FH = 3;                  // feature halo (7x7 window)
@@ -212,19 +219,42 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
 #pragma unroll
         for (int i = 0; i < 9; i++) md += __builtin_fabsf(win[i] - mean3) * (1.0f / 9.0f);
         fk[5] = md;
-        fk[6] = mad_procedure(win);
 
         const auto* wk = w + 70 * k;
 #pragma unroll
-        for (int g = 0; g < 7; g++)
+        for (int g = 0; g < 6; g++)
 #pragma unroll
             for (int nd = 0; nd < 10; nd++) a1[nd] = __builtin_fmaf(fk[g], wk[10 * g + nd], a1[nd]);
         if (features_out) {
 #pragma unroll
-            for (int g = 0; g < 7; g++) features_out[(size_t)(5 * g + k) * P + idx] = fk[g];
+            for (int g = 0; g < 6; g++) features_out[(size_t)(5 * g + k) * P + idx] = fk[g];
         }
     }
     if (features_out) features_out[(size_t)35 * P + idx] = inv_spp;
+
+    // The "MAD" of the five channels, unrolled side by side: each is one long
+    // chain of dependent compares and selects, and five independent chains in one
+    // block let the scheduler interleave them.
+    {
+        float mad[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float* tk = t + k * FPLANE + ly * FW + lx;
+            float win[9];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) win[j * 3 + i] = tk[(FH - 1 + j) * FW + FH - 1 + i];
+            mad[k] = mad_procedure(win);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+#pragma unroll
+            for (int nd = 0; nd < 10; nd++)
+                a1[nd] = __builtin_fmaf(mad[k], w[70 * k + 60 + nd], a1[nd]);
+            if (features_out) features_out[(size_t)(30 + k) * P + idx] = mad[k];
+        }
+    }
 
     float l2[10], l3[10];
 #pragma unroll
@@ -236,27 +266,47 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
 }
 
 // Loads the (32+6)x(8+6) tile of primaries (and their /49, /9 images) around
-// the block's outputs.
+// the block's outputs.  All of a thread's global loads are issued before the
+// first quotient is formed, so the tile costs one memory latency, not three.
 DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int x0, int y0,
                            float n, float* t)
 {
+    constexpr int EPT = (FPLANE + 255) / 256;
     const Recip three_n = make_recip(3.0f * n), one_n = make_recip(n);
     const Recip r49 = make_recip(49.0f), r9 = make_recip(9.0f);
-    for (int e = threadIdx.x; e < FPLANE; e += 256) {
-        int ty = e / FW, tx = e - ty * FW;
-        int gy = clampi(y0 + ty - FH, H), gx = clampi(x0 + tx - FH, W);
-        size_t gi = (size_t)gy * W + gx;
-        float q[5];
-        q[0] = primary3(planes + PTK_PL_NORMAL * P, P, gi, three_n);
-        q[1] = primary3(planes + PTK_PL_ALB1 * P, P, gi, three_n);
-        q[2] = primary3(planes + PTK_PL_ALB2 * P, P, gi, three_n);
-        q[3] = primary3(planes + PTK_PL_WPOS * P, P, gi, three_n);
-        q[4] = div_by(planes[PTK_PL_DL * P + gi], one_n);
+    float raw[EPT][13];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            t[k * FPLANE + e] = q[k];
-            t[(5 + k) * FPLANE + e] = div_by(q[k], r49);
-            t[(10 + k) * FPLANE + e] = div_by(q[k], r9);
+    for (int i = 0; i < EPT; i++) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < FPLANE) {
+            int ty = e / FW, tx = e - ty * FW;
+            int gy = clampi(y0 + ty - FH, H), gx = clampi(x0 + tx - FH, W);
+            size_t gi = (size_t)gy * W + gx;
+#pragma unroll
+            for (int k = 0; k < 13; k++) raw[i][k] = planes[(size_t)(PTK_PL_NORMAL + k) * P + gi];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < FPLANE) {
+            float q[5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // three separate quotients summed in order (DenoiserNN.cpp:16-36), bit-exact
+                float v = 0.0f;
+                v += div_by(raw[i][3 * k], three_n);
+                v += div_by(raw[i][3 * k + 1], three_n);
+                v += div_by(raw[i][3 * k + 2], three_n);
+                q[k] = v;
+            }
+            q[4] = div_by(raw[i][12], one_n);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                t[k * FPLANE + e] = q[k];
+                t[(5 + k) * FPLANE + e] = div_by(q[k], r49);
+                t[(10 + k) * FPLANE + e] = div_by(q[k], r9);
+            }
         }
     }
 }
@@ -326,13 +376,30 @@ DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int
     const int SW = TW + 2 * N, SH = TH + 2 * N;
     const int SS = SW * SH;
     const Recip dv = make_recip(nf);
-    for (int e = threadIdx.x; e < SS; e += 256) {
-        int ty = e / SW, tx = e - ty * SW;
-        int gy = clampi(y0 + ty - N, H), gx = clampi(x0 + tx - N, W);
-        size_t gi = (size_t)gy * W + gx;
+    // two elements' loads in flight per trip
+    for (int e0 = threadIdx.x; e0 < SS; e0 += 512) {
+        float raw[2][FV];
 #pragma unroll
-        for (int k = 0; k < 16; k++) t[k * SS + e] = div_by(planes[(size_t)k * P + gi], dv);
-        t[16 * SS + e] = planes[(size_t)PTK_PL_SD * P + gi];
+        for (int i = 0; i < 2; i++) {
+            const int e = e0 + 256 * i;
+            if (e < SS) {
+                int ty = e / SW, tx = e - ty * SW;
+                int gy = clampi(y0 + ty - N, H), gx = clampi(x0 + tx - N, W);
+                size_t gi = (size_t)gy * W + gx;
+#pragma unroll
+                for (int k = 0; k < 16; k++) raw[i][k] = planes[(size_t)k * P + gi];
+                raw[i][16] = planes[(size_t)PTK_PL_SD * P + gi];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = e0 + 256 * i;
+            if (e < SS) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) t[k * SS + e] = div_by(raw[i][k], dv);
+                t[16 * SS + e] = raw[i][16];
+            }
+        }
     }
 }
 
@@ -411,7 +478,7 @@ DEV void filter_pixel(const float* t, int SW, int SS, int ly, int lx, int N, con
 }
 
 template <int NFIX>
-__global__ __launch_bounds__(256, PTK_DN_WAVES) void filter_kernel(DenoiseArgs a)
+__global__ __launch_bounds__(256, PTK_DN_WAVES_FILTER) void filter_kernel(DenoiseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float ftile[];
     const int W = a.width, H = a.height, N = NFIX > 0 ? NFIX : a.n;
@@ -442,9 +509,113 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void filter_kernel(DenoiseArgs a
     a.wc_sum[idx] = wc;
 }
 
+// ---- filter, software-pipelined over a strip of tiles.
+//
+// A workgroup of the one-tile kernel above loads, waits, computes and stores in
+// turn, and three quarters of its waves' lifetime is spent parked on the tile
+// load.  Here a workgroup walks a sequence of tiles and holds the NEXT tile's
+// raw values in registers (global loads issued before the current tile's
+// taps are evaluated), so the loads of tile i+1 fly under the arithmetic of
+// tile i.  Workgroup b of XCD b % 8 takes tiles first + b / 8, + groups, ...
+// of that XCD's contiguous run of tiles: at any moment the resident workgroups
+// of an XCD cover a compact band of the image and share halos through its L2.
+#ifndef PTK_DN_WAVES_STRIP
+#define PTK_DN_WAVES_STRIP 3   // N = 1; wider windows stage more registers and take 2
+#endif
+struct StripSchedule {
+    int t, t_end, step, nbx;
+};
+DEV StripSchedule strip_schedule(const DenoiseArgs& a)
+{
+    StripSchedule s;
+    s.nbx = tiles_x(a);
+    const int nb = s.nbx * tiles_y(a), per = (nb + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7u);
+    s.step = (int)(gridDim.x >> 3);
+    s.t = xcd * per + (int)(blockIdx.x >> 3);
+    s.t_end = (xcd + 1) * per < nb ? (xcd + 1) * per : nb;
+    return s;
+}
+
+template <int N>
+__global__ __launch_bounds__(256, N == 1 ? PTK_DN_WAVES_STRIP : 2)
+void filter_strip_kernel(DenoiseArgs a)
+{
+    constexpr int SW = TW + 2 * N, SH = TH + 2 * N, SS = SW * SH;
+    constexpr int EPT = (SS + 255) / 256;   // tile elements staged per thread
+    extern __shared__ __attribute__((aligned(16))) float ftile[];
+    const int W = a.width, H = a.height;
+    const size_t P = (size_t)W * H;
+    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+    const Recip dv = make_recip((float)a.sample_count);
+    StripSchedule sc = strip_schedule(a);
+
+    float stage[EPT][FV];   // raw values of the next tile's elements
+    float sdv_next[13];     // the next tile's centre-pixel sd[6] and variances[7]
+    size_t idx_next = 0;
+    bool inside_next = false;
+    auto issue = [&](int t) {
+        const int x0 = (t % sc.nbx) * TW, y0 = a.row_begin + (t / sc.nbx) * TH;
+        const int x = x0 + lx, y = y0 + ly;
+        inside_next = x < W && y < a.row_end;
+        idx_next = inside_next ? (size_t)y * W + x : 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sdv_next[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx_next];
+#pragma unroll
+        for (int k = 0; k < 7; k++) sdv_next[6 + k] = a.variances[(size_t)k * P + idx_next];
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            const int e = tid + 256 * i;
+            if (e < SS) {
+                const int ty = e / SW, tx = e - ty * SW;
+                const int gy = clampi(y0 + ty - N, H), gx = clampi(x0 + tx - N, W);
+                const size_t gi = (size_t)gy * W + gx;
+#pragma unroll
+                for (int k = 0; k < 16; k++) stage[i][k] = a.planes[(size_t)k * P + gi];
+                stage[i][16] = a.planes[(size_t)PTK_PL_SD * P + gi];
+            }
+        }
+    };
+
+    if (sc.t < sc.t_end) issue(sc.t);
+    for (int t = sc.t; t < sc.t_end; t += sc.step) {
+        // the staged tile becomes the current one
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            const int e = tid + 256 * i;
+            if (e < SS) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) ftile[k * SS + e] = div_by(stage[i][k], dv);
+                ftile[16 * SS + e] = stage[i][16];
+            }
+        }
+        float sd[6], var[7];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sd[k] = sdv_next[k];
+#pragma unroll
+        for (int k = 0; k < 7; k++) var[k] = sdv_next[6 + k];
+        const size_t idx = idx_next;
+        const bool inside = inside_next;
+        __syncthreads();
+
+        if (t + sc.step < sc.t_end) issue(t + sc.step);   // in flight during the taps below
+
+        if (inside) {
+            float wsum[3], wc;
+            filter_pixel<N>(ftile, SW, SS, ly, lx, N, sd, var, wsum, wc);
+            const float inv = 1.0f / wc;
+            a.denoised[idx] = wsum[0] * inv;
+            a.denoised[P + idx] = wsum[1] * inv;
+            a.denoised[2 * P + idx] = wsum[2] * inv;
+            a.wc_sum[idx] = wc;
+        }
+        __syncthreads();   // the tile is overwritten at the top of the next iteration
+    }
+}
+
 // ---- fused: features + MLP for the centre pixel, then the filter, one launch.
 template <int NFIX>
-__global__ __launch_bounds__(256, PTK_DN_WAVES) void denoise_fused_kernel(DenoiseArgs a)
+__global__ __launch_bounds__(256, PTK_DN_WAVES_FUSED) void denoise_fused_kernel(DenoiseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int W = a.width, H = a.height, N = NFIX > 0 ? NFIX : a.n;
@@ -511,6 +682,47 @@ hipError_t launch_dyn(K kernel, const DenoiseArgs& a, size_t lds, hipStream_t st
 
 }  // namespace
 
+// Grid of a strip kernel: `per_cu` workgroups for each of the device's compute
+// units (a multiple of eight, one share per XCD), never more than one per tile.
+unsigned strip_grid(const DenoiseArgs& a, int per_cu)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return 0;
+        cus = prop.multiProcessorCount;
+    }
+    const unsigned tiles = (unsigned)((a.width + TW - 1) / TW) *
+                           (unsigned)((a.row_end - a.row_begin + TH - 1) / TH);
+    unsigned groups = (unsigned)cus * (unsigned)per_cu;
+    const unsigned per_xcd_tiles = (tiles + 7u) / 8u;
+    unsigned per_xcd = (groups + 7u) / 8u;
+    if (per_xcd > per_xcd_tiles) per_xcd = per_xcd_tiles;
+    return per_xcd * 8u;
+}
+
+template <class K>
+hipError_t launch_strip(K kernel, const DenoiseArgs& a, size_t lds, int per_cu, hipStream_t stream)
+{
+    const unsigned grid = strip_grid(a, per_cu);
+    if (grid == 0) return hipErrorInvalidDevice;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+#ifndef PTK_DN_STRIP
+#define PTK_DN_STRIP 1
+#endif
+#ifndef PTK_DN_STRIP_PER_CU
+#define PTK_DN_STRIP_PER_CU 3
+#endif
 hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
 {
     dim3 grid(denoise_grid(a));
@@ -521,6 +733,11 @@ hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
 hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
 {
     size_t lds = filter_lds_bytes(a.n);
+#if PTK_DN_STRIP
+    if (a.n == 1) return launch_strip(filter_strip_kernel<1>, a, lds, PTK_DN_STRIP_PER_CU, stream);
+    if (a.n == 2) return launch_strip(filter_strip_kernel<2>, a, lds, 2, stream);
+    if (a.n == 3) return launch_strip(filter_strip_kernel<3>, a, lds, 2, stream);
+#endif
     if (a.n == 1) return launch_dyn(filter_kernel<1>, a, lds, stream);
     return launch_dyn(filter_kernel<0>, a, lds, stream);
 }
