@@ -118,6 +118,13 @@ def denoise_probe(ctx, W, H, depth):
     e = sum(es[2:]) / len(es[2:])
     out["exposure_ms"] = e
     out["exposure_gbs"] = W * H * 12 / e / 1e6
+    ps = []
+    for _ in range(12):
+        ctx.post_process(0, 1.0, 2.2, want_post=False)
+        ps.append(ctx.timing().post_ms)
+    p = sum(ps[2:]) / len(ps[2:])
+    out["post_process_ms"] = p
+    out["post_process_gbs"] = W * H * 24 / p / 1e6
     return out
 
 

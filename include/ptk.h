@@ -98,6 +98,7 @@ typedef struct ptk_times {
     double denoise_ms;       /* features_ms + filter_ms (or the fused kernel)        */
     uint64_t render_samples; /* width*height*spp of the last ptk_render              */
     uint64_t render_rays;    /* bounce rays traced by the last ptk_render            */
+    double post_ms;          /* kernel of the last ptk_post_process                  */
 } ptk_times;
 
 /* Replaces CUDADenoiser::InitBuffers / CUDADenoiserNN::InitBuffers
@@ -201,6 +202,20 @@ int ptk_denoise_rows(ptk_ctx* ctx, const float w12[360], const float w23[100],
 /* Device addresses of the denoiser outputs (any pointer may be null). */
 int ptk_denoise_outputs_device(ptk_ctx* ctx, float** denoised_d, float** wc_sum_d,
                                float** variances_d);
+
+/* Replaces CUDARender::PostProcess (CUDARender.cu:959-1066): the display
+ * transform of the frame held by the context.  display_metric selects the source
+ * as the reference's displayMetric does: 0 colour / spp, 1 the last ptk_denoise
+ * output, 2 (normal / spp + 1) / 2, 3 albedo1 / spp, 4 albedo2 / spp,
+ * 5 directLight / spp, 6 1 / (worldPos / spp); 7 (the training target) is not
+ * held by the hot path and is PTK_ERR_ARG.  Then / exposure and pow(., 1 / g).
+ * post_screen (optional) receives the reference's postScreen: interleaved rgb,
+ * 3 * P floats.  rgb8 (optional) receives what PT::SaveImage writes
+ * (PT.cpp:484-501): int(255.999 * c) per channel, top row first, 3 * P bytes;
+ * NaN and out-of-range values, undefined in the reference's cast, clamp to
+ * [0, 255]. */
+int ptk_post_process(ptk_ctx* ctx, int display_metric, float exposure, float g,
+                     float* post_screen, uint8_t* rgb8);
 
 /* Replaces the chrono globals; see ptk_times. */
 int ptk_timing(ptk_ctx* ctx, ptk_times* out);

@@ -116,6 +116,11 @@ def lib():
         L.orc_tonemap8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.POINTER(C.c_uint8)]
         L.orc_tonemap8.restype = None
+        L.orc_post_process.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       C.c_float, fp]
+        L.orc_post_process.restype = C.c_int
+        L.orc_quantise8.argtypes = [fp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+        L.orc_quantise8.restype = None
         _lib = L
     return _lib
 
@@ -210,6 +215,26 @@ def filter(acc, variances, width, height, sample_count, n=1, threads=1, colour_v
     lib().orc_filter_variant(_fp(acc), _fp(variances), width, height, sample_count, n,
                              colour_variant, _fp(den), _fp(wc), threads)
     return den, wc
+
+
+def post_process(acc, denoised, width, height, sample_count, metric, exposure, gamma):
+    """CUDAPostProcess: returns the interleaved (P, 3) post screen."""
+    acc = np.ascontiguousarray(acc, dtype=np.float32)
+    den = None if denoised is None else np.ascontiguousarray(denoised, dtype=np.float32)
+    out = np.empty((width * height, 3), np.float32)
+    rc = lib().orc_post_process(_fp(acc), _fp(den) if den is not None else None, width, height,
+                                sample_count, metric, C.c_float(exposure), C.c_float(gamma),
+                                _fp(out))
+    if rc != 0:
+        raise ValueError("unsupported display metric %d" % metric)
+    return out
+
+
+def quantise8(post, width, height):
+    post = np.ascontiguousarray(post, dtype=np.float32)
+    out = np.empty((height, width, 3), np.uint8)
+    lib().orc_quantise8(_fp(post), width, height, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
 
 
 def tonemap8(acc, width, height, sample_count, exposure, gamma):

@@ -1161,6 +1161,51 @@ int orc_load_weights(const char* path, float* w12, float* w23, float* w34)
     return 0;
 }
 
+/* CUDAPostProcess (CUDARender.cu:959-1022): the display source of each metric
+ * (CUDARender::PostProcess, 1024-1066), then / exposure, then pow(., 1/g).
+ * `denoised` is the filter's output, interleaved (metric 1); metric 7 shows a
+ * training target the hot path does not hold and is rejected. */
+int orc_post_process(const float* acc, const float* denoised, int width, int height,
+                     int sample_count, int metric, float exposure, float gamma, float* post)
+{
+    size_t P = (size_t)width * (size_t)height;
+    float n = (float)sample_count;
+    if (metric < 0 || metric > 6 || (metric == 1 && !denoised)) return -1;
+    for (size_t i = 0; i < P; i++) {
+        float c[3];
+        for (int ch = 0; ch < 3; ch++) {
+            switch (metric) {
+            case 0: c[ch] = acc[(ORC_PL_COL + ch) * P + i] / n; break;
+            case 1: c[ch] = denoised[3 * i + ch]; break;
+            case 2: c[ch] = (acc[(ORC_PL_NORMAL + ch) * P + i] / n + 1.0f) / 2.0f; break;
+            case 3: c[ch] = acc[(ORC_PL_ALB1 + ch) * P + i] / n; break;
+            case 4: c[ch] = acc[(ORC_PL_ALB2 + ch) * P + i] / n; break;
+            case 5: c[ch] = acc[ORC_PL_DL * P + i] / n; break;
+            default: c[ch] = 1.0f / (acc[(ORC_PL_WPOS + ch) * P + i] / n); break;
+            }
+            c[ch] = c[ch] / exposure;
+            post[3 * i + ch] = (float)LM_POW(c[ch], 1.0f / gamma);
+        }
+    }
+    return 0;
+}
+
+/* PT::SaveImage's quantisation and row order (PT.cpp:484-501) of a post-processed
+ * screen; NaN and out-of-range values (undefined in the reference's cast) clamp. */
+void orc_quantise8(const float* post, int width, int height, uint8_t* out)
+{
+    for (int j = height - 1; j >= 0; --j)
+        for (int i = 0; i < width; ++i)
+            for (int ch = 0; ch < 3; ch++) {
+                float v = post[3 * ((size_t)j * width + i) + ch];
+                int q = (int)(255.999 * (double)v);
+                if (!(v == v)) q = 0;
+                if (q < 0) q = 0;
+                if (q > 255) q = 255;
+                *out++ = (uint8_t)q;
+            }
+}
+
 /* CUDAPostProcess mode 0 (CUDARender.cu:971-975, 1013-1020) followed by
  * PT::SaveImage's int(255.999 * c) and row flip (PT.cpp:484-501). */
 void orc_tonemap8(const float* acc, int width, int height, int sample_count,

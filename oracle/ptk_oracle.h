@@ -114,6 +114,13 @@ void orc_filter_variant(const float* acc, const float* variances7, int width, in
 
 int orc_load_weights(const char* path, float* w12, float* w23, float* w34);
 
+/* CUDAPostProcess for display metrics 0..6 (CUDARender.cu:959-1066): post is
+ * interleaved rgb, P * 3 floats.  Returns -1 for an unsupported metric. */
+int orc_post_process(const float* planes, const float* denoised_interleaved, int width, int height,
+                     int sample_count, int metric, float exposure, float gamma, float* post);
+/* PT::SaveImage quantisation, top row first (PT.cpp:484-501). */
+void orc_quantise8(const float* post, int width, int height, uint8_t* out_rgb_top_down);
+
 /* CUDAPostProcess display mode 0 + PT::SaveImage quantisation. */
 void orc_tonemap8(const float* rgb_sum_planes, int width, int height, int sample_count,
                   float exposure, float gamma, uint8_t* out_rgb_top_down);

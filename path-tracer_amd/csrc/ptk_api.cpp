@@ -69,6 +69,9 @@ struct ptk_ctx {
     float* features_d = nullptr;      // 36 planes (allocated on demand)
     float* denoised_d = nullptr;      // 3 planes
     float* wcsum_d = nullptr;         // 1 plane
+    float* post_d = nullptr;          // 3 planes (allocated on the first ptk_post_process)
+    uint8_t* rgb8_d = nullptr;        // 3 bytes per pixel (likewise)
+    bool have_denoised = false;
     float* staging_h = nullptr;       // pinned, for layout conversion on read-back
     size_t staging_floats = 0;
 
@@ -94,6 +97,9 @@ void free_image_buffers(ptk_ctx* c)
     (void)hipFree(c->features_d); c->features_d = nullptr;
     (void)hipFree(c->denoised_d); c->denoised_d = nullptr;
     (void)hipFree(c->wcsum_d); c->wcsum_d = nullptr;
+    (void)hipFree(c->post_d); c->post_d = nullptr;
+    (void)hipFree(c->rgb8_d); c->rgb8_d = nullptr;
+    c->have_denoised = false;
     if (c->staging_h) (void)hipHostFree(c->staging_h);
     c->staging_h = nullptr;
     c->staging_floats = 0;
@@ -598,6 +604,7 @@ int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* 
     a.row_begin = row_begin;
     a.row_end = row_end;
     if (row_begin == row_end) return PTK_OK;
+    c->have_denoised = true;
     if (variant == 0) {
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         HIP_TRY(ptk_launch_features_mlp(a, c->stream));
@@ -659,6 +666,52 @@ int ptk_denoise_outputs_device(ptk_ctx* c, float** denoised_d, float** wc_sum_d,
     if (denoised_d) *denoised_d = c->denoised_d;
     if (wc_sum_d) *wc_sum_d = c->wcsum_d;
     if (variances_d) *variances_d = c->variances_d;
+    return PTK_OK;
+}
+
+int ptk_post_process(ptk_ctx* c, int metric, float exposure, float g, float* post_screen,
+                     uint8_t* rgb8)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_post_process: null context");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_post_process before ptk_set_constants");
+    if (metric < 0 || metric > 6)
+        return fail(PTK_ERR_ARG, "ptk_post_process: display metric %d (0..6 supported)", metric);
+    if (metric == 1 && !c->have_denoised)
+        return fail(PTK_ERR_STATE, "ptk_post_process: metric 1 before ptk_denoise");
+    if (metric != 1 && c->sample_count < 1)
+        return fail(PTK_ERR_STATE, "ptk_post_process: no samples accumulated");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    const size_t P = c->pixels;
+    if (!c->post_d) HIP_TRY(hipMalloc((void**)&c->post_d, 3 * P * sizeof(float)));
+    if (rgb8 && !c->rgb8_d) HIP_TRY(hipMalloc((void**)&c->rgb8_d, 3 * P));
+
+    PostArgs a;
+    a.planes = c->planes_d;
+    a.denoised = c->denoised_d;
+    a.post = c->post_d;
+    a.rgb8 = rgb8 ? c->rgb8_d : nullptr;
+    a.pixels = P;
+    a.width = c->width;
+    a.height = c->height;
+    a.sample_count = c->sample_count;
+    a.metric = metric;
+    a.exposure = exposure;
+    a.inv_gamma = 1.0f / g;
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(ptk_launch_post_process(a, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, c->rgb8_d, 3 * P, hipMemcpyDeviceToHost, c->stream));
+    if (post_screen) {
+        if ((rc = ensure_staging(c, 3 * P)) != PTK_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->staging_h, c->post_d, 3 * P * sizeof(float),
+                               hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->times.post_ms = elapsed_ms(c);
+    if (post_screen)
+        for (size_t i = 0; i < P; i++)
+            for (int k = 0; k < 3; k++) post_screen[3 * i + k] = c->staging_h[(size_t)k * P + i];
     return PTK_OK;
 }
 

@@ -75,6 +75,17 @@ hipError_t ptk_launch_exposure(const float* planes, size_t pixels, int formula, 
 hipError_t ptk_launch_refresh_std_dev(float* planes, size_t pixels, int sample_count,
                                       hipStream_t stream);
 
+struct PostArgs {
+    const float* planes;     // accumulators
+    const float* denoised;   // 3 planes (metric 1)
+    float* post;             // 3 planes out
+    uint8_t* rgb8;           // 3 bytes per pixel, top row first; may be null
+    size_t pixels;
+    int32_t width, height, sample_count, metric;
+    float exposure, inv_gamma;
+};
+hipError_t ptk_launch_post_process(const PostArgs& a, hipStream_t stream);
+
 struct DenoiseArgs {
     const float* planes;
     const float* weights;   // 530 floats: w12, w23, w34 (device)

@@ -390,7 +390,7 @@ void Denoiser::denoise()
     st_->wcSum.resize(P);
     st_->variances.resize(7 * P);
     DenoiserNN& nn = st_->denoiserNN;
-    st_->check(ptk_denoise(st_->ctx, nn.onetwo, nn.twothree, nn.threefour, st_->denoisingN, 1,
+    st_->check(ptk_denoise(st_->ctx, nn.onetwo, nn.twothree, nn.threefour, st_->denoisingN, 0,
                            st_->denoisedCol.data(), st_->wcSum.data(), st_->variances.data(),
                            nullptr),
                "ptk_denoise");
@@ -450,12 +450,9 @@ void HostState::PostProcess(bool denoised)
 {
     size_t P = (size_t)xRes * yRes;
     postScreen.resize(3 * P);
-    const std::vector<float>& src = denoised ? denoisedCol : preScreen;
-    for (size_t i = 0; i < 3 * P; i++) {
-        float c = denoised ? src[i] : src[i] / (float)sampleCount;
-        c = c / exposure;
-        postScreen[i] = powf(c, 1.0f / g);
-    }
+    check(ptk_post_process(ctx, denoised ? 1 : displayMetric, exposure, g, postScreen.data(),
+                           nullptr),
+          "ptk_post_process");
 }
 
 bool HostState::SaveImage(const std::string& path) const

@@ -146,8 +146,10 @@ struct HostState {
     // Copies the device accumulators into the host screens (what the reference's
     // CUDA backend does in its host loop, CUDARender.cu:886-929).
     void SyncScreens();
-    // CUDAPostProcess mode 0 / 1 (CUDARender.cu:959-1022): col/spp (or the
-    // denoised colour), / exposure, pow(1/g) -> postScreen.
+    // CUDARender::PostProcess (CUDARender.cu:959-1066) on the device: the source
+    // named by displayMetric (or the denoised colour), / exposure, pow(1/g) ->
+    // postScreen.
+    int displayMetric = 0;
     void PostProcess(bool denoised);
     // PT::SaveImage (PT.cpp:484-501): ASCII P3, rows flipped, int(255.999*c).
     bool SaveImage(const std::string& path) const;

@@ -24,7 +24,8 @@ EXPORTS = [
     "ptk_set_math_mode", "ptk_set_stream_id", "ptk_render", "ptk_read_accumulators",
     "ptk_read_planes", "ptk_write_planes", "ptk_planes_device", "ptk_get_sample_count",
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
-    "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_timing", "ptk_synchronize",
+    "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_timing",
+    "ptk_synchronize",
 ]
 
 
@@ -35,7 +36,8 @@ class PtkError(RuntimeError):
 class Times(C.Structure):
     _fields_ = [("render_ms", C.c_double), ("seed_ms", C.c_double), ("exposure_ms", C.c_double),
                 ("features_ms", C.c_double), ("filter_ms", C.c_double), ("denoise_ms", C.c_double),
-                ("render_samples", C.c_uint64), ("render_rays", C.c_uint64)]
+                ("render_samples", C.c_uint64), ("render_rays", C.c_uint64),
+                ("post_ms", C.c_double)]
 
 
 _lib = None
@@ -71,6 +73,7 @@ def load():
     L.ptk_denoise.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]
     L.ptk_denoise_rows.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ptk_denoise_outputs_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.ptk_post_process.argtypes = [vp, C.c_int, C.c_float, C.c_float, fp, C.POINTER(C.c_uint8)]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
     for name in EXPORTS:
@@ -222,6 +225,15 @@ class Context:
         self._check(self._L.ptk_denoise_outputs_device(self._h, C.byref(d), C.byref(w),
                                                        C.byref(v)))
         return int(d.value), int(w.value), int(v.value)
+
+    def post_process(self, metric=0, exposure=1.0, g=2.2, want_post=True, want_rgb8=False):
+        """Returns (postScreen (P, 3) float32 | None, rgb8 (H, W, 3) uint8 top row first | None)."""
+        post = np.empty((self.pixels, 3), np.float32) if want_post else None
+        rgb = np.empty((self.height, self.width, 3), np.uint8) if want_rgb8 else None
+        self._check(self._L.ptk_post_process(
+            self._h, metric, C.c_float(exposure), C.c_float(g), _fp(post),
+            rgb.ctypes.data_as(C.POINTER(C.c_uint8)) if rgb is not None else None))
+        return post, rgb
 
     def timing(self):
         t = Times()

@@ -290,3 +290,33 @@ def test_denoise_row_bands_tile_the_full_result(ctx, oracle):
         ctx.denoise_rows(w, 1, 0, 10, 5)
     with pytest.raises(ptk.PtkError):
         ctx.denoise_rows(w, 1, 0, 0, H + 1)
+
+
+def test_post_process_matches_the_display_transform(ctx, oracle):
+    """Display metrics 0..6: float screen within 2e-6 relative of the CPU restatement (pow is
+    evaluated in double here, by libm's powf there); 8-bit output identical except where a
+    value sits within that distance of a quantisation step."""
+    import ptk
+    O = oracle
+    W, H = 96, 54
+    sc = O.load_scene(scene_path("MultiLightGlass"))
+    ctx.set_constants(O.build_constants(sc, W, H, 4, 0.005, True))
+    ctx.render(6, ptk.SEED_COUNTER)
+    planes = ctx.read_planes()
+    w = O.load_weights(weights_path("BEST"))
+    with pytest.raises(ptk.PtkError):
+        ctx.post_process(1, 1.0, 2.2)                      # nothing denoised yet
+    den = ctx.denoise(w, 1, 0)["denoised"]
+    for metric, exposure, g in ((0, 1.0, 2.2), (0, 0.37, 1.0), (1, 1.3, 2.2), (2, 1.0, 2.2),
+                                (3, 1.0, 1.7), (4, 2.0, 2.2), (5, 1.0, 2.2), (6, 1.0, 2.2)):
+        ref = O.post_process(planes, den, W, H, 6, metric, exposure, g)
+        post, rgb = ctx.post_process(metric, exposure, g, want_rgb8=True)
+        assert _rel_ok(post, ref, 2e-6).all(), metric
+        ref8 = O.quantise8(ref, W, H)
+        assert (rgb != ref8).mean() < 1e-3
+        assert np.abs(rgb.astype(int) - ref8.astype(int)).max() <= 1
+        # the library's own float screen quantises to exactly its 8-bit output
+        assert np.array_equal(rgb, O.quantise8(post, W, H))
+    with pytest.raises(ptk.PtkError):
+        ctx.post_process(7, 1.0, 2.2)
+    assert ctx.timing().post_ms > 0.0

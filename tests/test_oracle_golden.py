@@ -84,3 +84,19 @@ def test_weight_files_have_530_values():
     for name in ("BEST", "init", "box_grid", "NNWeights"):
         lines = open(weights_path(name)).read().splitlines()
         assert [len(l.split()) for l in lines[:3]] == [360, 100, 70]
+
+
+def test_post_process_metric0_is_the_tonemap(oracle):
+    """The general display transform at metric 0, quantised, equals the mode-0 tone-map."""
+    g = np.load(os.path.join(GOLDEN, "render_cornell_64x36.npz"))
+    acc = g["acc_8spp"]
+    post = oracle.post_process(acc, None, 64, 36, 8, 0, 0.8, 2.2)
+    assert np.array_equal(oracle.quantise8(post, 64, 36).reshape(-1),
+                          np.asarray(oracle.tonemap8(acc, 64, 36, 8, 0.8, 2.2)).reshape(-1))
+    with pytest.raises(ValueError):
+        oracle.post_process(acc, None, 64, 36, 8, 1, 1.0, 2.2)    # metric 1 needs a denoised image
+    with pytest.raises(ValueError):
+        oracle.post_process(acc, None, 64, 36, 8, 7, 1.0, 2.2)
+    # metric 2 maps normals from [-1, 1] to [0, 1]
+    n = oracle.post_process(acc, None, 64, 36, 8, 2, 1.0, 1.0)
+    assert np.nanmin(n) >= -1e-6 and np.nanmax(n) <= 1.0 + 1e-6
