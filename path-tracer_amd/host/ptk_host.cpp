@@ -504,3 +504,20 @@ extern "C" int ptkhost_load_weights(const char* path, float* w12, float* w23, fl
     std::memcpy(w34, st.denoiserNN.threefour, 70 * sizeof(float));
     return 0;
 }
+
+extern "C" int ptkhost_resave_scene(const char* in_path, const char* out_path)
+{
+    if (!in_path || !out_path) return -1;
+    ptkhost::HostState st;
+    if (!st.scene.LoadScene(in_path)) return -1;
+    return st.scene.SaveScene(out_path) ? 0 : -1;
+}
+
+extern "C" int ptkhost_resave_weights(const char* in_path, const char* out_path)
+{
+    if (!in_path || !out_path) return -1;
+    ptkhost::HostState st;
+    if (!st.denoiserNN.LoadWeights(in_path)) return -1;
+    st.denoiserNN.OutputWeights(out_path);
+    return 0;
+}

@@ -171,4 +171,8 @@ int ptkhost_scene_constants(const char* scene_path, int width, int height, int m
                             float* exposure_out, float* gamma_out);
 // Reads a three-line weights file.  Returns 0 or -1.
 int ptkhost_load_weights(const char* path, float* w12_360, float* w23_100, float* w34_70);
+// Scene::LoadScene then Scene::SaveScene / LoadWeights then OutputWeights: the
+// on-disk formats either side of the hot path, for round-trip checks.
+int ptkhost_resave_scene(const char* in_path, const char* out_path);
+int ptkhost_resave_weights(const char* in_path, const char* out_path);
 }

@@ -265,6 +265,9 @@ def _load_host():
         H.ptkhost_load_weights.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                            C.POINTER(C.c_float)]
         H.ptkhost_load_weights.restype = C.c_int
+        for fn in (H.ptkhost_resave_scene, H.ptkhost_resave_weights):
+            fn.argtypes = [C.c_char_p, C.c_char_p]
+            fn.restype = C.c_int
         _host = H
     return _host
 
@@ -288,3 +291,15 @@ def load_weights(path):
     if rc != 0:
         raise PtkError("cannot load weights %s" % path)
     return w12, w23, w34
+
+
+def resave_scene(in_path, out_path):
+    """Scene::LoadScene then Scene::SaveScene."""
+    if _load_host().ptkhost_resave_scene(os.fsencode(in_path), os.fsencode(out_path)) != 0:
+        raise PtkError("cannot re-save scene %s" % in_path)
+
+
+def resave_weights(in_path, out_path):
+    """DenoiserNN::LoadWeights then DenoiserNN::OutputWeights."""
+    if _load_host().ptkhost_resave_weights(os.fsencode(in_path), os.fsencode(out_path)) != 0:
+        raise PtkError("cannot re-save weights %s" % in_path)
