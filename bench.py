@@ -79,11 +79,34 @@ def cpu_baseline(scene, W, H, depth):
         O.render(consts, acc, more, 1 + spp, seed, threads=threads)
         dt = time.perf_counter() - t0
         spp = more
-    return {
+    out = {
         "value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
         "sample": "%s %dx%d, %d spp, maxDepth %d, OpenMP over rows with pre-generated "
                   "reference seeds (oracle/ptk_oracle.c)" % (scene, W, H, spp, depth),
     }
+    # one thread on a quarter-size image (the reference's own default is sequential)
+    w4, h4 = W // 2, H // 2
+    c4 = O.build_constants(sc, w4, h4, depth, 0.005, False)
+    a4 = O.new_accumulators(w4, h4)
+    t0 = time.perf_counter()
+    O.render(c4, a4, 2, 0, seed, threads=1)
+    out["single_thread_msamples_per_s"] = w4 * h4 * 2 / (time.perf_counter() - t0) / 1e6
+    # denoiser inference on the host cores: configs[2]'s scene at 8 spp, N = 1
+    scd = O.load_scene(os.path.join(ROOT, "data", "scenes", "MultiLightGlass.scene"))
+    cd = O.build_constants(scd, W, H, depth, 0.005, True)
+    ad = O.new_accumulators(W, H)
+    O.render(cd, ad, 8, 0, seed, threads=threads)
+    wts = O.load_weights(os.path.join(ROOT, "data", "weights", "BEST.txt"))
+    t0 = time.perf_counter()
+    _, var = O.forward_prop(ad, W, H, 8, wts, threads=threads)
+    t1 = time.perf_counter()
+    O.filter(ad, var, W, H, 8, 1, threads=threads)
+    t2 = time.perf_counter()
+    out["denoise_ms"] = (t2 - t0) * 1e3
+    out["denoise_features_ms"] = (t1 - t0) * 1e3
+    out["denoise_filter_ms"] = (t2 - t1) * 1e3
+    out["denoise_sample"] = "MultiLightGlass %dx%d, 8 spp, BEST.txt, N=1, %d threads" % (W, H, threads)
+    return out
 
 
 def denoise_probe(ctx, W, H, depth):
@@ -125,6 +148,19 @@ def denoise_probe(ctx, W, H, depth):
     p = sum(ps[2:]) / len(ps[2:])
     out["post_process_ms"] = p
     out["post_process_gbs"] = W * H * 24 / p / 1e6
+    # what a plain device copy achieves on this board, for scale (read + write counted)
+    n = 1 << 28
+    src = torch.empty(n, dtype=torch.float32, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    ev1.record()
+    torch.cuda.synchronize()
+    out["device_copy_gbs"] = 5 * 2 * n * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     return out
 
 
@@ -174,10 +210,13 @@ def main():
 
     spp = args.spp_per_step
     kernel_ms = []
+    kernel_rays = []
 
     def step():
         ctx.render(spp, ptk.SEED_COUNTER)
-        kernel_ms.append(ctx.timing().render_ms)
+        t = ctx.timing()
+        kernel_ms.append(t.render_ms)
+        kernel_rays.append(t.render_rays)
         if world > 1:
             # per-frame accumulation exchange: sum of the colour planes over ranks
             frame.copy_(planes[0:3])
@@ -196,6 +235,7 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
+    kernel_rays.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -234,6 +274,7 @@ def main():
                 "bound": "valu", "kernel": "render_kernel", "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": None, "avg_launch_ms": avg_ms,
+                "grays_per_s": sum(kernel_rays) / max(sum(kernel_ms), 1e-9) / 1e6,
                 "flops_per_sample": flops, "int_ops_per_sample": ops.get("int_ops_per_sample"),
                 "algorithmic_bytes": 2 * 3 * 4 * W * H,   # colour planes read + written once
                 "note": "fp32 VALU bound (not HBM, not MFMA): algorithmic flops per sample from "

@@ -208,7 +208,8 @@ int ptk_denoise_outputs_device(ptk_ctx* ctx, float** denoised_d, float** wc_sum_
  * as the reference's displayMetric does: 0 colour / spp, 1 the last ptk_denoise
  * output, 2 (normal / spp + 1) / 2, 3 albedo1 / spp, 4 albedo2 / spp,
  * 5 directLight / spp, 6 1 / (worldPos / spp); 7 (the training target) is not
- * held by the hot path and is PTK_ERR_ARG.  Then / exposure and pow(., 1 / g).
+ * held by the hot path and is PTK_ERR_ARG.  Then / exposure and pow(., 1 / g)
+ * (within 1e-6 relative of powf).
  * post_screen (optional) receives the reference's postScreen: interleaved rgb,
  * 3 * P floats.  rgb8 (optional) receives what PT::SaveImage writes
  * (PT.cpp:484-501): int(255.999 * c) per channel, top row first, 3 * P bytes;

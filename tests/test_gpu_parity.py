@@ -293,9 +293,9 @@ def test_denoise_row_bands_tile_the_full_result(ctx, oracle):
 
 
 def test_post_process_matches_the_display_transform(ctx, oracle):
-    """Display metrics 0..6: float screen within 2e-6 relative of the CPU restatement (pow is
-    evaluated in double here, by libm's powf there); 8-bit output identical except where a
-    value sits within that distance of a quantisation step."""
+    """Display metrics 0..6: float screen within 2e-6 relative of the CPU restatement (the
+    gamma power is exp2(log2(v) / g) on the hardware units here, libm's powf there); 8-bit
+    output identical except where a value sits within that distance of a quantisation step."""
     import ptk
     O = oracle
     W, H = 96, 54
