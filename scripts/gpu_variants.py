@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd
 import ptk
 W, H, spp = 1920, 1080, 32
 ctx = ptk.Context(0)
-for scene in ("cornell_crystal", "Box_Grid"):
+for scene in ("cornell_crystal", "Box_Grid", "MultiLightGlass"):
   for feats in (False, True):
     raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", scene + ".scene"), W, H, 4, 0.005, feats)
     ctx.set_constants(raw); ctx.render(2, ptk.SEED_COUNTER)
