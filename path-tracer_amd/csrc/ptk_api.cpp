@@ -183,6 +183,17 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
             for (int i = 0; i < 3; i++) { o.lo[i] = at[3 + i]; o.hi[i] = at[6 + i]; }
             for (int i = 0; i < 4; i++) o.q[i] = at[9 + i];
             o.rotated = (at[10] + at[11] + at[12] > E) ? 1 : 0;
+            {
+                // r = q in the first product, l = conj(q) in the second
+                // (Renderers.cpp:25-47); every entry is one fp32 operation
+                const float rw = o.q[0], rx = o.q[1], ry = o.q[2], rz = o.q[3];
+                const float lw = o.q[0], lx = -o.q[1], ly = -o.q[2], lz = -o.q[3];
+                float* t = d.rot[s];
+                t[0] = rx + ry; t[1] = rw + rz; t[2] = rw - rz; t[3] = rx - ry;
+                t[4] = ry - rz; t[5] = rx + rw; t[6] = ry + rz; t[7] = rw - rx;
+                t[8] = lz + lx; t[9] = lw - ly; t[10] = lw + ly; t[11] = lz - lx;
+                t[12] = lz - ly; t[13] = lx + lw; t[14] = lw - lx; t[15] = lz + ly;
+            }
             for (int i = 2; i >= 0; i--)
                 if (std::fabs(o.lo[i] - o.hi[i]) < E) o.flat_axis = i;
             for (int i = 0; i < 3; i++)

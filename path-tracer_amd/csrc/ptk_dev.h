@@ -42,6 +42,11 @@ struct DevScene {
     float imp_boost;   // (float)num_imp when num_imp > 1, else 1
     DevShape shape[PTK_MAX_SHAPES];
     float mats[PTK_MAX_MATS][6];
+    // Per shape, the sixteen sums of quaternion components that the two
+    // quaternion products of a world-to-box rotation form from the box's
+    // quaternion alone (same fp32 additions, done once on the host): [0..7] for
+    // (0,v) * q, [8..15] for conj(q) * (that product).  Read only for rotated boxes.
+    float rot[PTK_MAX_SHAPES][16];
 };
 
 struct RenderArgs {
