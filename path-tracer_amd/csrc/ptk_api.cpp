@@ -119,6 +119,39 @@ int ensure_staging(ptk_ctx* c, size_t floats)
 // Scene POD -> device layout.  Derived values are computed here in fp32 with
 // the reference's operation order so the kernel reads what it would have
 // computed itself (this translation unit is built without FMA contraction).
+// The reference's quaternion product and rotation (Renderers.cpp:25-47) and its
+// normalisation, in fp32 with no contraction (this file is built with
+// -ffp-contract=off): the same operations, in the same order, as the kernel's.
+struct Quat { float w, x, y, z; };
+Quat quat_mul_host(Quat l, Quat r)
+{
+    float a1 = (l.z + l.x) * (r.x + r.y);
+    float a3 = (l.w - l.y) * (r.w + r.z);
+    float a4 = (l.w + l.y) * (r.w - r.z);
+    float a2 = a1 + a3 + a4;
+    float a5 = (l.z - l.x) * (r.x - r.y);
+    a5 = (a5 + a2) / 2.0f;
+    Quat o;
+    o.w = a5 - a1 + (l.z - l.y) * (r.y - r.z);
+    o.x = a5 - a2 + (l.x + l.w) * (r.x + r.w);
+    o.y = a5 - a3 + (l.w - l.x) * (r.y + r.z);
+    o.z = a5 - a4 + (l.z + l.y) * (r.w - r.x);
+    return o;
+}
+void face_normal_host(const float q[4], const float n[3], float out[3])
+{
+    Quat p = {0.0f, n[0], n[1], n[2]};
+    Quat qc = {q[0], -q[1], -q[2], -q[3]};     // the normal is rotated back by the conjugate
+    Quat qcc = {qc.w, -qc.x, -qc.y, -qc.z};
+    p = quat_mul_host(p, qc);
+    qcc = quat_mul_host(qcc, p);
+    volatile float len2 = qcc.x * qcc.x + qcc.y * qcc.y + qcc.z * qcc.z;
+    float len = std::sqrt((float)len2);
+    out[0] = qcc.x / len;
+    out[1] = qcc.y / len;
+    out[2] = qcc.z / len;
+}
+
 int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
 {
     if (k.res_h <= 0 || k.res_v <= 0 || (int64_t)k.res_h * k.res_v > (int64_t)1 << 28)
@@ -193,6 +226,11 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
                 t[4] = ry - rz; t[5] = rx + rw; t[6] = ry + rz; t[7] = rw - rx;
                 t[8] = lz + lx; t[9] = lw - ly; t[10] = lw + ly; t[11] = lz - lx;
                 t[12] = lz - ly; t[13] = lx + lw; t[14] = lw - lx; t[15] = lz + ly;
+            }
+            for (int face = 0; face < 7; face++) {
+                float n[3] = {0.0f, 0.0f, 0.0f};
+                if (face > 0) n[(face - 1) / 2] = (face & 1) ? -1.0f : 1.0f;
+                face_normal_host(o.q, n, d.face_normal[s][face]);
             }
             for (int i = 2; i >= 0; i--)
                 if (std::fabs(o.lo[i] - o.hi[i]) < E) o.flat_axis = i;

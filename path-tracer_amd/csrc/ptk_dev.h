@@ -47,6 +47,11 @@ struct DevScene {
     // quaternion alone (same fp32 additions, done once on the host): [0..7] for
     // (0,v) * q, [8..15] for conj(q) * (that product).  Read only for rotated boxes.
     float rot[PTK_MAX_SHAPES][16];
+    // Per box, the world-space normal of each face code (0 none, 1 -x, 2 +x,
+    // 3 -y, 4 +y, 5 -z, 6 +z): the box-space unit normal rotated by conj(q) and
+    // normalised, evaluated on the host with the kernel's fp32 operations in
+    // the kernel's order (Renderers.cpp:25-47, 262-267).
+    float face_normal[PTK_MAX_SHAPES][7][3];
 };
 
 struct RenderArgs {
