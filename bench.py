@@ -148,6 +148,13 @@ def denoise_probe(ctx, W, H, depth):
     p = sum(ps[2:]) / len(ps[2:])
     out["post_process_ms"] = p
     out["post_process_gbs"] = W * H * 24 / p / 1e6
+    # one training step's reductions (relMSE + back-prop sums) with this frame as its own target
+    ctx.save_target()
+    ts = []
+    for _ in range(6):
+        ctx.train_step(w, 1, 1e-6)
+        ts.append(ctx.timing().train_ms)
+    out["train_reduce_ms"] = sum(ts[1:]) / len(ts[1:])
     # what a plain device copy achieves on this board, for scale (read + write counted)
     n = 1 << 28
     src = torch.empty(n, dtype=torch.float32, device="cuda")

@@ -99,6 +99,7 @@ typedef struct ptk_times {
     uint64_t render_samples; /* width*height*spp of the last ptk_render              */
     uint64_t render_rays;    /* bounce rays traced by the last ptk_render            */
     double post_ms;          /* kernel of the last ptk_post_process                  */
+    double train_ms;         /* reduction kernel of the last ptk_train_step          */
 } ptk_times;
 
 /* Replaces CUDADenoiser::InitBuffers / CUDADenoiserNN::InitBuffers
@@ -217,6 +218,27 @@ int ptk_denoise_outputs_device(ptk_ctx* ctx, float** denoised_d, float** wc_sum_
  * [0, 255]. */
 int ptk_post_process(ptk_ctx* ctx, int display_metric, float exposure, float g,
                      float* post_screen, uint8_t* rgb8);
+
+/* Replaces Denoiser::saveTargetCol (Denoiser.cpp:148-155): the training target
+ * becomes the current colour sums / sample count, on the device. */
+int ptk_save_target(ptk_ctx* ctx);
+
+/* Sets the training target from host memory: interleaved rgb, 3 * P floats (the
+ * reference's targetCol). */
+int ptk_set_target(ptk_ctx* ctx, const float* target);
+
+/* One training epoch's arithmetic after the render (DenoiserNN::TrainNN,
+ * DenoiserNN.cpp:1520-1563): denoiser.denoise() with the given weights (forward
+ * pass keeping the 36 features and both hidden layers, then the filter, window
+ * n), GenRelMSE (DenoiserNN.cpp:1461-1474) into rel_mse (optional), and BackProp
+ * in its sequential CPU form (CPUBackProp / CPUFilterDerivative,
+ * DenoiserNN.cpp:959-1103, followed as written), which updates the three weight
+ * arrays in place.  The reference accumulates the update pixel by pixel in fp32;
+ * here the 56 sums are reduced in double on the device and added once.  Images
+ * taller than wide are PTK_ERR_ARG: the reference's filter derivative indexes
+ * pixel (j, i) as j * yRes + i (DenoiserNN.cpp:964-967), which leaves the image. */
+int ptk_train_step(ptk_ctx* ctx, float w12[360], float w23[100], float w34[70], int n,
+                   float learning_rate, float* rel_mse);
 
 /* Replaces the chrono globals; see ptk_times. */
 int ptk_timing(ptk_ctx* ctx, ptk_times* out);

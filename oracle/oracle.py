@@ -116,6 +116,14 @@ def lib():
         L.orc_tonemap8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.POINTER(C.c_uint8)]
         L.orc_tonemap8.restype = None
+        L.orc_forward_prop_layers.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp,
+                                              fp, C.c_int]
+        L.orc_forward_prop_layers.restype = None
+        L.orc_rel_mse.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int]
+        L.orc_rel_mse.restype = C.c_float
+        L.orc_back_prop.argtypes = [fp] * 8 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp, fp,
+                                               fp]
+        L.orc_back_prop.restype = C.c_int
         L.orc_post_process.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                        C.c_float, fp]
         L.orc_post_process.restype = C.c_int
@@ -215,6 +223,36 @@ def filter(acc, variances, width, height, sample_count, n=1, threads=1, colour_v
     lib().orc_filter_variant(_fp(acc), _fp(variances), width, height, sample_count, n,
                              colour_variant, _fp(den), _fp(wc), threads)
     return den, wc
+
+
+def forward_prop_layers(acc, width, height, sample_count, weights, threads=1):
+    """Returns (features (P,36), variances (P,7), layer2 (P,10), layer3 (P,10))."""
+    P = width * height
+    w12, w23, w34 = (np.ascontiguousarray(w, dtype=np.float32) for w in weights)
+    feats, var = np.empty((P, 36), np.float32), np.empty((P, 7), np.float32)
+    l2, l3 = np.empty((P, 10), np.float32), np.empty((P, 10), np.float32)
+    lib().orc_forward_prop_layers(_fp(acc), width, height, sample_count, _fp(w12), _fp(w23),
+                                  _fp(w34), _fp(feats), _fp(var), _fp(l2), _fp(l3), threads)
+    return feats, var, l2, l3
+
+
+def rel_mse(denoised, target, width, height, sample_count):
+    d = np.ascontiguousarray(denoised, dtype=np.float32)
+    t = np.ascontiguousarray(target, dtype=np.float32)
+    return float(lib().orc_rel_mse(_fp(d), _fp(t), width, height, sample_count))
+
+
+def back_prop(acc, denoised, wc_sum, variances, feats, l2, l3, target, width, height,
+              sample_count, n, learning_rate, weights):
+    """CPUBackProp: returns the updated (w12, w23, w34)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float32)
+            for a in (acc, denoised, wc_sum, variances, feats, l2, l3, target)]
+    w12, w23, w34 = (np.array(w, dtype=np.float32, copy=True) for w in weights)
+    rc = lib().orc_back_prop(*[_fp(a) for a in arrs], width, height, sample_count, n,
+                             C.c_float(learning_rate), _fp(w12), _fp(w23), _fp(w34))
+    if rc != 0:
+        raise ValueError("back-prop is undefined for images taller than wide")
+    return w12, w23, w34
 
 
 def post_process(acc, denoised, width, height, sample_count, metric, exposure, gamma):

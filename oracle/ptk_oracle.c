@@ -33,6 +33,7 @@ typedef double lm_t;
 #define LM_SIN(x) sin((double)(x))
 #define LM_ACOS(x) acos((double)(x))
 #define LM_POW(x, y) pow((double)(x), (double)(y))
+#define LM_EXP(x) exp((double)(x))
 #else
 typedef float lm_t;
 #define LM_SQRT(x) sqrtf(x)
@@ -40,6 +41,7 @@ typedef float lm_t;
 #define LM_SIN(x) sinf(x)
 #define LM_ACOS(x) acosf(x)
 #define LM_POW(x, y) powf(x, y)
+#define LM_EXP(x) expf(x)
 #endif
 static const float EPS = 0.00001f;    /* Renderers.cpp:113 */
 
@@ -809,9 +811,25 @@ static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 static inline float softplusf(float x) { return logf(1.0f + expf(x)); }
 
 /* CPUForwardProp, DenoiserNN.cpp:12-301. */
+void orc_forward_prop_layers(const float* acc, int width, int height, int sample_count,
+                             const float* w12, const float* w23, const float* w34,
+                             float* features36, float* variances7, float* layer2, float* layer3,
+                             int threads);
+
 void orc_forward_prop(const float* acc, int width, int height, int sample_count,
                       const float* w12, const float* w23, const float* w34,
                       float* features36, float* variances7, int threads)
+{
+    orc_forward_prop_layers(acc, width, height, sample_count, w12, w23, w34, features36,
+                            variances7, NULL, NULL, threads);
+}
+
+/* As orc_forward_prop, also keeping layerTwoValues / layerThreeValues (10 per
+ * pixel each, DenoiserNN.cpp:271-284) when the pointers are not NULL. */
+void orc_forward_prop_layers(const float* acc, int width, int height, int sample_count,
+                             const float* w12, const float* w23, const float* w34,
+                             float* features36, float* variances7, float* layer2, float* layer3,
+                             int threads)
 {
     int W = width, H = height;
     size_t P = (size_t)W * (size_t)H;
@@ -911,9 +929,130 @@ void orc_forward_prop(const float* acc, int width, int height, int sample_count,
                 for (int w = 0; w < 10; w++) a += l3[w] * w34[10 * node + w];
                 variances7[7 * idx + node] = softplusf(a);
             }
+            if (layer2) memcpy(layer2 + 10 * idx, l2, sizeof l2);
+            if (layer3) memcpy(layer3 + 10 * idx, l3, sizeof l3);
         }
     }
     free(prim);
+}
+
+/* ------------------------------------------------------ denoiser: training */
+
+/* DenoiserNN::GenRelMSE (DenoiserNN.cpp:1461-1474): sequential fp32. */
+float orc_rel_mse(const float* denoised, const float* target, int width, int height,
+                  int sample_count)
+{
+    size_t P = (size_t)width * (size_t)height;
+    float rel = 0.0f;
+    for (size_t i = 0; i < P; i++)
+        for (int ch = 0; ch < 3; ch++) {
+            float d = denoised[3 * i + ch] - target[3 * i + ch];
+            float t = target[3 * i + ch];
+            rel += d * d / (t * t + 0.00001f);
+        }
+    rel *= (float)sample_count / 2.0f;
+    return rel;
+}
+
+/* The seven vectors CPUFilterDerivative(j, i, var) returns for var = 0..6
+ * (DenoiserNN.cpp:959-1054), as written: the flat index of "pixel (j, i)" is
+ * j * yRes + i and its neighbours clamp rows at xRes - 1 and columns at
+ * yRes - 1 (tW = yRes, tH = xRes); the spatial term uses the absolute j and i;
+ * the colour difference is the raw sum minus the filtered colour. */
+static void filter_derivative(const float* acc, const float* denoised, const float* wc_sum,
+                              const float* variances7, int xRes, int yRes, int sample_count,
+                              int nwin, int j, int i, float out[7][3])
+{
+    size_t P = (size_t)xRes * (size_t)yRes;
+    int tW = yRes, tH = xRes;
+    size_t iIndex = (size_t)j * tW + i;
+    float n = (float)sample_count;
+    const float* var = variances7 + 7 * iIndex;
+    float sd_i[6];
+    for (int k = 0; k < 6; k++) sd_i[k] = acc[(ORC_PL_SD + k) * P + iIndex];
+    const int plane[5] = {ORC_PL_COL, ORC_PL_NORMAL, ORC_PL_ALB1, ORC_PL_ALB2, ORC_PL_WPOS};
+    for (int v = 0; v < 7; v++) out[v][0] = out[v][1] = out[v][2] = 0.0f;
+
+    for (int j1 = -nwin; j1 <= nwin; j1++) {
+        for (int i1 = -nwin; i1 <= nwin; i1++) {
+            size_t jIndex = (size_t)(j + j1 < 0 ? 0 : (j + j1 >= tH ? tH - 1 : j + j1));
+            jIndex *= tW;
+            jIndex += (size_t)(i + i1 < 0 ? 0 : (i + i1 >= tW ? tW - 1 : i + i1));
+
+            float vecSum[3];
+            for (int ch = 0; ch < 3; ch++)
+                vecSum[ch] = (acc[(ORC_PL_COL + ch) * P + jIndex] - denoised[3 * iIndex + ch]) /
+                             wc_sum[iIndex];
+
+            float pd[7], dv[7];
+            pd[0] = (float)(LM_POW((float)j, 2) + LM_POW((float)i, 2));
+            dv[0] = pd[0] / (2.0f * var[0] + 0.000001f);
+            for (int k = 0; k < 5; k++) {
+                lm_t s2 = 0;
+                for (int ch = 0; ch < 3; ch++) {
+                    float a = acc[(plane[k] + ch) * P + iIndex] / n;
+                    float b = acc[(plane[k] + ch) * P + jIndex] / n;
+                    s2 += LM_POW(a - b, 2);
+                }
+                pd[1 + k] = (float)s2;
+            }
+            {
+                float a = acc[ORC_PL_DL * P + iIndex] / n, b = acc[ORC_PL_DL * P + jIndex] / n;
+                pd[6] = (float)LM_POW(a - b, 2);
+            }
+            float sd0_j = acc[ORC_PL_SD * P + jIndex];
+            dv[1] = pd[1] / (2.0f * var[1] * (sd_i[0] + sd0_j) + 0.000001f);
+            for (int k = 2; k < 7; k++) dv[k] = pd[k] / (2.0f * var[k] * sd_i[k - 1] + 0.000001f);
+
+            float mult = 1.0f;
+            for (int k = 0; k < 7; k++) mult *= (float)LM_EXP(-dv[k]) + 0.000001f;
+
+            for (int v = 0; v < 7; v++) {
+                float wop = (float)(mult * pd[v] / LM_POW(var[v], 3));
+                for (int ch = 0; ch < 3; ch++) out[v][ch] += vecSum[ch] * wop;
+            }
+        }
+    }
+}
+
+/* DenoiserNN::CPUBackProp (DenoiserNN.cpp:1056-1103): in-place update of the
+ * three weight arrays, sequential over pixels, as written.  `target` and
+ * `denoised` are interleaved rgb; features36 / layer2 / layer3 as produced by
+ * orc_forward_prop_layers. */
+int orc_back_prop(const float* acc, const float* denoised, const float* wc_sum,
+                  const float* variances7, const float* features36, const float* layer2,
+                  const float* layer3, const float* target, int width, int height,
+                  int sample_count, int nwin, float learning_rate, float* w12, float* w23,
+                  float* w34)
+{
+    int xRes = width, yRes = height;
+    /* CPUFilterDerivative's flat index j * yRes + i leaves the image when the
+     * image is taller than wide: undefined in the reference, refused here. */
+    if (yRes > xRes) return -1;
+    float n = (float)sample_count;
+    for (int j = 0; j < yRes; j++) {
+        for (int i = 0; i < xRes; i++) {
+            size_t pixel = (size_t)j * xRes + i;
+            float eoc[3];
+            for (int ch = 0; ch < 3; ch++) {
+                float t = target[3 * pixel + ch];
+                eoc[ch] = n * (denoised[3 * pixel + ch] - t) / (t * t + 0.0001f);
+            }
+            float cop[7][3];
+            filter_derivative(acc, denoised, wc_sum, variances7, xRes, yRes, sample_count, nwin, j,
+                              i, cop);
+            for (int v = 0; v < 7; v++) {
+                float dot = eoc[0] * cop[v][0] + eoc[1] * cop[v][1] + eoc[2] * cop[v][2];
+                for (int w = 0; w < 360; w++)
+                    w12[w] += learning_rate * dot * features36[36 * pixel + w % 36];
+                for (int w = 0; w < 100; w++)
+                    w23[w] += learning_rate * dot * layer2[10 * pixel + w % 10];
+                for (int w = 0; w < 70; w++)
+                    w34[w] += learning_rate * dot * layer3[10 * pixel + w % 10];
+            }
+        }
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------- denoiser: filter */

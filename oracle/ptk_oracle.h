@@ -103,6 +103,26 @@ void orc_forward_prop(const float* acc, int width, int height, int sample_count,
                       const float* w12, const float* w23, const float* w34,
                       float* features36, float* variances7, int threads);
 
+/* As orc_forward_prop, also returning layerTwoValues / layerThreeValues (10 per
+ * pixel each, DenoiserNN.cpp:271-284) when not NULL: what training keeps. */
+void orc_forward_prop_layers(const float* acc, int width, int height, int sample_count,
+                             const float* w12, const float* w23, const float* w34,
+                             float* features36, float* variances7, float* layer2, float* layer3,
+                             int threads);
+
+/* DenoiserNN::GenRelMSE (DenoiserNN.cpp:1461-1474); images interleaved rgb. */
+float orc_rel_mse(const float* denoised, const float* target, int width, int height,
+                  int sample_count);
+
+/* DenoiserNN::CPUBackProp with CPUFilterDerivative (DenoiserNN.cpp:959-1103),
+ * as written: updates the three weight arrays in place.  Returns -1 (nothing
+ * done) when height > width, where the reference indexes out of bounds. */
+int orc_back_prop(const float* acc, const float* denoised, const float* wc_sum,
+                  const float* variances7, const float* features36, const float* layer2,
+                  const float* layer3, const float* target, int width, int height,
+                  int sample_count, int nwin, float learning_rate, float* w12, float* w23,
+                  float* w34);
+
 /* CPUDenoise: denoised (3*P pixel-major rgb), wc_sum (P). */
 void orc_filter(const float* acc, const float* variances7, int width, int height,
                 int sample_count, int n, float* denoised, float* wc_sum, int threads);

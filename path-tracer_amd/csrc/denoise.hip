@@ -160,7 +160,7 @@ DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 // 5 mean deviation, 6 "MAD") and channel k is 5*g + k; index 35 is 1/spp.
 DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5], float inv_spp,
                           const __attribute__((address_space(4))) float* w, float* features_out,
-                          size_t P, size_t idx, float (&var)[7])
+                          float* layers_out, size_t P, size_t idx, float (&var)[7])
 {
     float a1[10];
 #pragma unroll
@@ -263,6 +263,13 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
     for (int nd = 0; nd < 10; nd++) l3[nd] = sigmoid(dot_w<10>(l2, w + 360 + 10 * nd));
 #pragma unroll
     for (int nd = 0; nd < 7; nd++) var[nd] = softplus(dot_w<10>(l3, w + 460 + 10 * nd));
+    if (layers_out) {   // layerTwoValues / layerThreeValues, kept for training
+#pragma unroll
+        for (int nd = 0; nd < 10; nd++) {
+            layers_out[(size_t)nd * P + idx] = l2[nd];
+            layers_out[(size_t)(10 + nd) * P + idx] = l3[nd];
+        }
+    }
 }
 
 // Loads the (32+6)x(8+6) tile of primaries (and their /49, /9 images) around
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
 
     float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, a.features, P, idx, var);
+    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, a.features, a.layers, P, idx, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
 }
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES_FUSED) void denoise_fused_kernel(
     float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
     const float sd5[5] = {sd[1], sd[2], sd[3], sd[4], sd[5]};
-    features_and_mlp(ptile, ly, lx, sd5, 1.0f / n, w, nullptr, P, idx, var);
+    features_and_mlp(ptile, ly, lx, sd5, 1.0f / n, w, nullptr, nullptr, P, idx, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
     float wsum[3], wc;

@@ -69,6 +69,10 @@ struct ptk_ctx {
     float* features_d = nullptr;      // 36 planes (allocated on demand)
     float* denoised_d = nullptr;      // 3 planes
     float* wcsum_d = nullptr;         // 1 plane
+    float* layers_d = nullptr;        // 20 planes (allocated on the first ptk_train_step)
+    float* target_d = nullptr;        // 3 planes (allocated when a target is set)
+    double* train_sums_d = nullptr;   // PTK_TRAIN_SUM_DOUBLES
+    bool have_target = false;
     float* post_d = nullptr;          // 3 planes (allocated on the first ptk_post_process)
     uint8_t* rgb8_d = nullptr;        // 3 bytes per pixel (likewise)
     bool have_denoised = false;
@@ -98,6 +102,9 @@ void free_image_buffers(ptk_ctx* c)
     (void)hipFree(c->denoised_d); c->denoised_d = nullptr;
     (void)hipFree(c->wcsum_d); c->wcsum_d = nullptr;
     (void)hipFree(c->post_d); c->post_d = nullptr;
+    (void)hipFree(c->layers_d); c->layers_d = nullptr;
+    (void)hipFree(c->target_d); c->target_d = nullptr;
+    c->have_target = false;
     (void)hipFree(c->rgb8_d); c->rgb8_d = nullptr;
     c->have_denoised = false;
     if (c->staging_h) (void)hipHostFree(c->staging_h);
@@ -609,7 +616,8 @@ namespace {
 // Uploads the weights and runs the denoiser on rows [row_begin, row_end); the
 // results stay in the context's device planes.
 int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* w34, int n,
-                   int variant, int row_begin, int row_end, bool want_features)
+                   int variant, int row_begin, int row_end, bool want_features,
+                   bool want_layers = false)
 {
     if (!c || !w12 || !w23 || !w34) return fail(PTK_ERR_ARG, "ptk_denoise: null argument");
     if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_denoise before ptk_set_constants");
@@ -644,6 +652,9 @@ int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* 
     a.weights = c->weights_d;
     a.variances = c->variances_d;
     a.features = want_features ? c->features_d : nullptr;
+    if (want_layers && !c->layers_d)
+        HIP_TRY(hipMalloc((void**)&c->layers_d, 20 * P * sizeof(float)));
+    a.layers = want_layers ? c->layers_d : nullptr;
     a.denoised = c->denoised_d;
     a.wc_sum = c->wcsum_d;
     a.width = c->width;
@@ -715,6 +726,89 @@ int ptk_denoise_outputs_device(ptk_ctx* c, float** denoised_d, float** wc_sum_d,
     if (denoised_d) *denoised_d = c->denoised_d;
     if (wc_sum_d) *wc_sum_d = c->wcsum_d;
     if (variances_d) *variances_d = c->variances_d;
+    return PTK_OK;
+}
+
+int ptk_save_target(ptk_ctx* c)
+{
+    if (!c) return fail(PTK_ERR_ARG, "ptk_save_target: null context");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_save_target before ptk_set_constants");
+    if (c->sample_count < 1) return fail(PTK_ERR_STATE, "ptk_save_target: no samples accumulated");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    if (!c->target_d) HIP_TRY(hipMalloc((void**)&c->target_d, 3 * c->pixels * sizeof(float)));
+    HIP_TRY(ptk_launch_save_target(c->planes_d, c->target_d, c->pixels, c->sample_count, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_target = true;
+    return PTK_OK;
+}
+
+int ptk_set_target(ptk_ctx* c, const float* target)
+{
+    if (!c || !target) return fail(PTK_ERR_ARG, "ptk_set_target: null argument");
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_set_target before ptk_set_constants");
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    const size_t P = c->pixels;
+    if (!c->target_d) HIP_TRY(hipMalloc((void**)&c->target_d, 3 * P * sizeof(float)));
+    if ((rc = ensure_staging(c, 3 * P)) != PTK_OK) return rc;
+    for (size_t i = 0; i < P; i++)
+        for (int k = 0; k < 3; k++) c->staging_h[(size_t)k * P + i] = target[3 * i + k];
+    HIP_TRY(hipMemcpyAsync(c->target_d, c->staging_h, 3 * P * sizeof(float), hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_target = true;
+    return PTK_OK;
+}
+
+int ptk_train_step(ptk_ctx* c, float* w12, float* w23, float* w34, int n, float learning_rate,
+                   float* rel_mse)
+{
+    if (!c || !w12 || !w23 || !w34) return fail(PTK_ERR_ARG, "ptk_train_step: null argument");
+    if (!c->have_target)
+        return fail(PTK_ERR_STATE, "ptk_train_step before ptk_save_target / ptk_set_target");
+    if (c->height > c->width)
+        return fail(PTK_ERR_ARG, "ptk_train_step: %dx%d is taller than wide; the reference's filter "
+                    "derivative (DenoiserNN.cpp:964-967) indexes outside the image there",
+                    c->width, c->height);
+    // forward pass keeping the features and both hidden layers, then the filter
+    int rc = denoise_device(c, w12, w23, w34, n, 0, 0, c->height, true, true);
+    if (rc != PTK_OK) return rc;
+    if (!c->train_sums_d)
+        HIP_TRY(hipMalloc((void**)&c->train_sums_d, PTK_TRAIN_SUM_DOUBLES * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->train_sums_d, 0, PTK_TRAIN_SUM_DOUBLES * sizeof(double), c->stream));
+    TrainArgs a;
+    a.planes = c->planes_d;
+    a.denoised = c->denoised_d;
+    a.wc_sum = c->wcsum_d;
+    a.variances = c->variances_d;
+    a.features = c->features_d;
+    a.layers = c->layers_d;
+    a.target = c->target_d;
+    a.sums = c->train_sums_d;
+    a.width = c->width;
+    a.height = c->height;
+    a.sample_count = c->sample_count;
+    a.n = n;
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(ptk_launch_train(a, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    double shards[PTK_TRAIN_SUM_DOUBLES];
+    HIP_TRY(hipMemcpyAsync(shards, c->train_sums_d, sizeof shards, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->times.train_ms = elapsed_ms(c);
+    double sum[PTK_TRAIN_TERMS];
+    for (int k = 0; k < PTK_TRAIN_TERMS; k++) {
+        sum[k] = 0.0;
+        for (int sh = 0; sh < PTK_TRAIN_SHARDS; sh++) sum[k] += shards[sh * PTK_TRAIN_TERMS + k];
+    }
+    if (rel_mse) *rel_mse = (float)(sum[0] * ((double)c->sample_count / 2.0));
+    // every weight of a layer whose index is congruent modulo the fan-in gets the same
+    // increment (DenoiserNN.cpp:1083-1098)
+    for (int w = 0; w < 360; w++) w12[w] += (float)((double)learning_rate * sum[1 + w % 36]);
+    for (int w = 0; w < 100; w++) w23[w] += (float)((double)learning_rate * sum[37 + w % 10]);
+    for (int w = 0; w < 70; w++) w34[w] += (float)((double)learning_rate * sum[47 + w % 10]);
     return PTK_OK;
 }
 

@@ -101,6 +101,7 @@ struct DenoiseArgs {
     const float* weights;   // 530 floats: w12, w23, w34 (device)
     float* variances;       // 7 planes, plane-major (device)
     float* features;        // 36 planes, plane-major, or null
+    float* layers;          // 20 planes (second- and third-layer activations), or null
     float* denoised;        // 3 planes, plane-major
     float* wc_sum;          // 1 plane
     int32_t width, height;
@@ -109,5 +110,31 @@ struct DenoiseArgs {
     int32_t row_begin, row_end;  // rows [row_begin, row_end) are produced (a band, or the image)
 };
 hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream);
+
+// One training step's reductions (DenoiserNN::GenRelMSE and CPUBackProp,
+// DenoiserNN.cpp:959-1103, 1461-1474).  sums (device, PTK_TRAIN_SUM_DOUBLES
+// doubles, zeroed by the caller) receives, sharded over PTK_TRAIN_SHARDS
+// copies that the host adds up: [0] the relMSE sum, [1..36] sum of G * feature,
+// [37..46] sum of G * layer-two value, [47..56] sum of G * layer-three value,
+// where G is the pixel's sum over the seven filter parameters of
+// dot(error over colour, colour over parameter).
+#define PTK_TRAIN_TERMS 57
+#define PTK_TRAIN_SHARDS 16
+#define PTK_TRAIN_SUM_DOUBLES (PTK_TRAIN_TERMS * PTK_TRAIN_SHARDS)
+struct TrainArgs {
+    const float* planes;     // accumulators
+    const float* denoised;   // 3 planes
+    const float* wc_sum;     // 1 plane
+    const float* variances;  // 7 planes
+    const float* features;   // 36 planes
+    const float* layers;     // 20 planes
+    const float* target;     // 3 planes
+    double* sums;
+    int32_t width, height, sample_count, n;
+};
+hipError_t ptk_launch_train(const TrainArgs& a, hipStream_t stream);
+// target = colour sums / sample count (Denoiser::saveTargetCol, Denoiser.cpp:148-155)
+hipError_t ptk_launch_save_target(const float* planes, float* target, size_t pixels,
+                                  int sample_count, hipStream_t stream);
 hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream);
 hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream);

@@ -17,7 +17,9 @@ static void usage()
                  "usage: ptk_headless --scene FILE [--res WxH] [--spp N] [--depth D]\n"
                  "       [--rand-samp F] [--seed HEX0,HEX1 | --counter-seeds] [--fast]\n"
                  "       [--auto-exposure] [--denoise N --weights FILE] [--device K]\n"
-                 "       [--ppm OUT.ppm] [--dump PREFIX]\n");
+                 "       [--ppm OUT.ppm] [--dump PREFIX]\n"
+                 "       [--train EPOCHS --train-spp N --lr-exp X --save-weights FILE]\n"
+                 "         (the rendered frame becomes the target; needs --denoise N)\n");
 }
 
 static bool dump(const std::string& path, const std::vector<float>& v)
@@ -29,7 +31,9 @@ static bool dump(const std::string& path, const std::vector<float>& v)
 
 int main(int argc, char** argv)
 {
-    std::string scene, weights, ppm, prefix;
+    std::string scene, weights, ppm, prefix, save_weights;
+    int epochs = 0, train_spp = 4;
+    float lr_exp = 5.0f;
     int W = 1536, H = 864, spp = 16, depth = 4, nwin = -1, device = 0;
     float rand_samp = 0.005f;
     bool counter = false, fast = false, auto_exp = false, have_seed = false;
@@ -55,6 +59,10 @@ int main(int argc, char** argv)
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--ppm") ppm = next();
         else if (a == "--dump") prefix = next();
+        else if (a == "--train") epochs = std::atoi(next());
+        else if (a == "--train-spp") train_spp = std::atoi(next());
+        else if (a == "--lr-exp") lr_exp = (float)std::atof(next());
+        else if (a == "--save-weights") save_weights = next();
         else { usage(); return 2; }
     }
     if (scene.empty()) { usage(); return 2; }
@@ -82,8 +90,27 @@ int main(int argc, char** argv)
         std::printf("auto exposure: %.9g (%.4f ms)\n", st.exposure, st.exposureTime);
     }
     bool denoised = false;
+    if (epochs > 0) {
+        // the frame just rendered is the target; each epoch renders a fresh noisy frame
+        if (nwin < 0) { std::fprintf(stderr, "--train needs --denoise N\n"); return 1; }
+        if (!weights.empty() && !st.denoiserNN.LoadWeights(weights)) {
+            std::fprintf(stderr, "cannot read %s\n", weights.c_str());
+            return 1;
+        }
+        st.denoiserNN.samplesWhenTraining = train_spp;
+        st.denoiserNN.lRateInt = st.denoiserNN.lRateIntMax = lr_exp;
+        st.denoiserNN.InitTraining();
+        for (int e = 0; e < epochs && st.ok(); e++) {
+            st.denoiserNN.TrainNN();
+            std::printf("epoch %d: relMSE %.6g  lr %.3g  %.3f ms\n", e, st.denoiserNN.relMSE,
+                        st.denoiserNN.learningRate, st.denoiserNN.epochTime);
+        }
+        if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
+        if (!save_weights.empty()) st.denoiserNN.OutputWeights(save_weights);
+        weights.clear();   // the trained weights are in place for the denoise below
+    }
     if (nwin >= 0) {
-        if (weights.empty() || !st.denoiserNN.LoadWeights(weights)) {
+        if (epochs == 0 && (weights.empty() || !st.denoiserNN.LoadWeights(weights))) {
             std::fprintf(stderr, "--denoise needs --weights FILE\n");
             return 1;
         }

@@ -376,6 +376,64 @@ void DenoiserNN::ForwardProp()
                "ptk_denoise");
 }
 
+void DenoiserNN::RandomizeWeights()
+{
+    // xoroshiro128++ on the renderer's global state, (double)u64 / 2^63 / 2 scaled to
+    // [-0.5, 0.5] (DenoiserNN.cpp:1567-1601)
+    auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+    uint64_t* S = st_->renderer.GloRandS;
+    auto next = [&]() {
+        const uint64_t s0 = S[0];
+        uint64_t s1 = S[1];
+        const uint64_t r = rotl(s0 + s1, 17) + s0;
+        s1 ^= s0;
+        S[0] = rotl(s0, 49) ^ s1 ^ (s1 << 21);
+        S[1] = rotl(s1, 28);
+        return r;
+    };
+    auto between = [&](float lo, float hi) {
+        double f = (double)next() / (double)(1ULL << 63) / 2.0;
+        f *= hi - lo;
+        f += lo;
+        return (float)f;
+    };
+    for (float& w : onetwo) w = between(-0.5f, 0.5f);
+    for (float& w : twothree) w = between(-0.5f, 0.5f);
+    for (int i = 0; i < 70; i++) threefour[i] = between(-0.5f, 0.5f);
+}
+
+void DenoiserNN::InitTraining()
+{
+    if (!st_->ctx) { st_->lastError = "DenoiserNN::InitTraining before UpdateConstants"; return; }
+    training = true;
+    st_->check(ptk_save_target(st_->ctx), "ptk_save_target");
+    if (!st_->weightsLoaded) RandomizeWeights();
+    st_->weightsLoaded = true;
+    trainingEpoch = 0;
+}
+
+void DenoiserNN::TrainNN()
+{
+    if (!st_->ctx) { st_->lastError = "DenoiserNN::TrainNN before UpdateConstants"; return; }
+    float inv = lRateInt;
+    if (trainingLimitBool)
+        inv = lRateInt + (lRateIntMax - lRateInt) * ((float)trainingEpoch / (float)trainingCount);
+    learningRate = (float)(1.0 / std::pow(10.0, (double)inv));
+
+    st_->check(ptk_reset_accumulators(st_->ctx), "ptk_reset_accumulators");
+    st_->sampleCount = 0;
+    st_->renderer.Render(samplesWhenTraining);
+    if (!st_->ok()) return;
+    st_->check(ptk_train_step(st_->ctx, onetwo, twothree, threefour, st_->denoisingN, learningRate,
+                              &relMSE),
+               "ptk_train_step");
+    if (!st_->ok()) return;
+    ptk_times t;
+    if (ptk_timing(st_->ctx, &t) == PTK_OK) epochTime = t.denoise_ms + t.train_ms;
+    trainingEpoch++;
+    if (trainingLimitBool && trainingEpoch == trainingCount) training = false;
+}
+
 // --------------------------------------------------------------- Denoiser
 
 void Denoiser::denoise()

@@ -91,6 +91,20 @@ public:
     void ForwardProp();  // headers/DenoiserNN.h:103-131; fills variances (and sFeatures)
     float onetwo[360] = {0}, twothree[100] = {0}, threefour[80] = {0};
 
+    // Training (DenoiserNN.cpp:1476-1563).  InitTraining takes the current frame
+    // as the target (Denoiser::saveTargetCol) and keeps the loaded weights, or
+    // randomises them when none are loaded; TrainNN is one epoch: a fresh frame
+    // of samplesWhenTraining samples, denoise + relMSE + back-prop in one
+    // device call (ptk_train_step), epoch counter and learning-rate schedule.
+    void InitTraining();
+    void TrainNN();
+    void RandomizeWeights();                      // DenoiserNN.cpp:1591-1601
+    bool training = false, trainingLimitBool = false;
+    int trainingEpoch = 0, trainingCount = 0, samplesWhenTraining = 4;
+    float lRateInt = 5.0f, lRateIntMax = 5.0f;    // learningRate = 10^-lRateInt
+    float learningRate = 0.0001f, relMSE = 0.0f;
+    double epochTime = 0.0;                       // ms, device time of the reductions
+
 private:
     HostState* st_;
 };

@@ -24,8 +24,8 @@ EXPORTS = [
     "ptk_set_math_mode", "ptk_set_stream_id", "ptk_render", "ptk_read_accumulators",
     "ptk_read_planes", "ptk_write_planes", "ptk_planes_device", "ptk_get_sample_count",
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
-    "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_timing",
-    "ptk_synchronize",
+    "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_save_target",
+    "ptk_set_target", "ptk_train_step", "ptk_timing", "ptk_synchronize",
 ]
 
 
@@ -37,7 +37,7 @@ class Times(C.Structure):
     _fields_ = [("render_ms", C.c_double), ("seed_ms", C.c_double), ("exposure_ms", C.c_double),
                 ("features_ms", C.c_double), ("filter_ms", C.c_double), ("denoise_ms", C.c_double),
                 ("render_samples", C.c_uint64), ("render_rays", C.c_uint64),
-                ("post_ms", C.c_double)]
+                ("post_ms", C.c_double), ("train_ms", C.c_double)]
 
 
 _lib = None
@@ -74,6 +74,9 @@ def load():
     L.ptk_denoise_rows.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ptk_denoise_outputs_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.ptk_post_process.argtypes = [vp, C.c_int, C.c_float, C.c_float, fp, C.POINTER(C.c_uint8)]
+    L.ptk_save_target.argtypes = [vp]
+    L.ptk_set_target.argtypes = [vp, fp]
+    L.ptk_train_step.argtypes = [vp, fp, fp, fp, C.c_int, C.c_float, fp]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
     for name in EXPORTS:
@@ -234,6 +237,22 @@ class Context:
             self._h, metric, C.c_float(exposure), C.c_float(g), _fp(post),
             rgb.ctypes.data_as(C.POINTER(C.c_uint8)) if rgb is not None else None))
         return post, rgb
+
+    def save_target(self):
+        self._check(self._L.ptk_save_target(self._h))
+
+    def set_target(self, target):
+        t = np.ascontiguousarray(target, dtype=np.float32)
+        assert t.size == 3 * self.pixels
+        self._check(self._L.ptk_set_target(self._h, _fp(t)))
+
+    def train_step(self, weights, n=1, learning_rate=1e-4):
+        """One TrainNN epoch after the render: returns (updated (w12, w23, w34), relMSE)."""
+        w12, w23, w34 = (np.array(w, dtype=np.float32, copy=True) for w in weights)
+        rel = np.zeros(1, np.float32)
+        self._check(self._L.ptk_train_step(self._h, _fp(w12), _fp(w23), _fp(w34), n,
+                                           C.c_float(learning_rate), _fp(rel)))
+        return (w12, w23, w34), float(rel[0])
 
     def timing(self):
         t = Times()

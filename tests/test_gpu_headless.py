@@ -59,3 +59,23 @@ def test_headless_rejects_bad_arguments(tmp_path):
     r = subprocess.run([HEADLESS, "--scene", str(tmp_path / "missing.scene")], capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 1
+
+
+def test_headless_training_epochs(tmp_path):
+    """--train: the rendered frame becomes the target, each epoch renders a fresh noisy frame
+    and takes one step; the weights written afterwards load back and differ from the start."""
+    import ptk
+    out_w = str(tmp_path / "trained.txt")
+    cmd = [HEADLESS, "--scene", scene_path("cornell"), "--res", "96x54", "--spp", "64",
+           "--counter-seeds", "--denoise", "1", "--weights", weights_path("box_grid"),
+           "--train", "3", "--train-spp", "4", "--lr-exp", "4", "--save-weights", out_w,
+           "--ppm", str(tmp_path / "t.ppm")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rel = [float(l.split("relMSE")[1].split()[0]) for l in r.stdout.splitlines()
+           if l.startswith("epoch")]
+    assert len(rel) == 3 and all(np.isfinite(rel)) and all(x > 0 for x in rel)
+    w0, w1 = ptk.load_weights(weights_path("box_grid")), ptk.load_weights(out_w)
+    assert all(np.isfinite(b).all() for b in w1)
+    assert any(not np.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(w0, w1))
+    assert _read_ppm(str(tmp_path / "t.ppm")).shape == (54, 96, 3)

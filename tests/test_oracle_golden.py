@@ -100,3 +100,35 @@ def test_post_process_metric0_is_the_tonemap(oracle):
     # metric 2 maps normals from [-1, 1] to [0, 1]
     n = oracle.post_process(acc, None, 64, 36, 8, 2, 1.0, 1.0)
     assert np.nanmin(n) >= -1e-6 and np.nanmax(n) <= 1.0 + 1e-6
+
+
+def test_training_restatement_structure(oracle):
+    """GenRelMSE / CPUBackProp restatement ("parity unpinned": the reference recorded no
+    training output): relMSE vanishes on a perfect target, the update is linear in the learning
+    rate, repeats with each layer's fan-in, and portrait images (where the reference's filter
+    derivative indexes outside the image) are refused."""
+    O = oracle
+    W, H, spp = 40, 24, 6
+    sc = O.load_scene(scene_path("cornell"))
+    acc = O.new_accumulators(W, H)
+    O.render(O.build_constants(sc, W, H, 4, 0.005, True), acc, spp, 0, (11, 12), threads=4)
+    w = O.load_weights(weights_path("box_grid"))
+    feats, var, l2, l3 = O.forward_prop_layers(acc, W, H, spp, w, threads=2)
+    f0, v0 = O.forward_prop(acc, W, H, spp, w, threads=2)
+    assert np.array_equal(feats, f0) and np.array_equal(var, v0)
+    assert np.all((l2 >= 0) & (l2 <= 1)) and np.all((l3 >= 0) & (l3 <= 1))   # sigmoid outputs
+    den, wc = O.filter(acc, var, W, H, spp, 1)
+    assert O.rel_mse(den, den, W, H, spp) == 0.0
+    target = (acc[0:3].T / spp) * 0.8 + 0.05
+    assert O.rel_mse(den, target, W, H, spp) > 0.0
+    zero = tuple(np.zeros_like(x) for x in w)
+    d1 = O.back_prop(acc, den, wc, var, feats, l2, l3, target, W, H, spp, 1, 1e-3, zero)
+    d2 = O.back_prop(acc, den, wc, var, feats, l2, l3, target, W, H, spp, 1, 2e-3, zero)
+    for a, b, fan in zip(d1, d2, (36, 10, 10)):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert np.allclose(2 * a, b, rtol=1e-4, atol=1e-9)
+        assert np.allclose(a[:fan], a[fan:2 * fan], rtol=1e-5, atol=1e-9)
+    same = O.back_prop(acc, den, wc, var, feats, l2, l3, target, W, H, spp, 1, 0.0, w)
+    assert all(np.array_equal(a, b) for a, b in zip(same, w))
+    with pytest.raises(ValueError):
+        O.back_prop(acc, den, wc, var, feats, l2, l3, target, H, W, spp, 1, 1e-3, w)
