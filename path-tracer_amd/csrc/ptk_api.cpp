@@ -251,6 +251,14 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
             area += dx * dz * 2.0f;
             o.area = area;
         }
+        ScanRec& r = d.scan[s];
+        for (int i = 0; i < 3; i++) { r.c[i] = o.c[i]; r.lo[i] = o.lo[i]; r.hi[i] = o.hi[i]; }
+        r.rsq = o.rsq;
+        r.type = o.type;
+        r.rotated = o.rotated;
+        r.same_mask = o.same_mask;
+        r.mat_type = o.mat_type;
+        r.mat = o.mat;
     }
     return PTK_OK;
 }

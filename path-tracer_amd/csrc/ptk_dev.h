@@ -32,6 +32,17 @@ struct DevShape {
 };
 static_assert(sizeof(DevShape) == 25 * 4, "DevShape must be 25 dwords");
 
+// What a scan over the shapes reads of each shape, as one 64-byte record so a
+// single 16-dword scalar load fetches it (and the next record can be requested
+// while the current one is tested).
+struct alignas(64) ScanRec {
+    float c[3], lo[3], hi[3];
+    float rsq;
+    int32_t type, rotated, same_mask, mat_type, mat;
+    int32_t pad;
+};
+static_assert(sizeof(ScanRec) == 64, "ScanRec must be 16 dwords");
+
 struct DevScene {
     float cam_pos[3], cam_fwd[3], cam_right[3], cam_up[3];
     float rand_samp, max_angle_v, max_angle_h, focal;
@@ -52,6 +63,7 @@ struct DevScene {
     // normalised, evaluated on the host with the kernel's fp32 operations in
     // the kernel's order (Renderers.cpp:25-47, 262-267).
     float face_normal[PTK_MAX_SHAPES][7][3];
+    ScanRec scan[PTK_MAX_SHAPES + 1];   // one past the end so the look-ahead load is always valid
 };
 
 struct RenderArgs {
