@@ -325,6 +325,7 @@ int ptk_destroy(ptk_ctx* c)
     (void)hipFree(c->rays_d);
     (void)hipFree(c->sum_d);
     (void)hipFree(c->weights_d);
+    (void)hipFree(c->train_sums_d);
     if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
     if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -1,13 +1,20 @@
 // render_fast.hip -- PTK_MATH_FAST instantiation of the path-trace kernel:
-// reciprocal-based slab tests and normalisation, hardware sin/cos, FMA
-// contraction.  Same sampling decisions and estimator; values differ from
-// EXACT mode at the 1e-6 relative level per operation.
+// reciprocal-based slab tests and normalisation, hardware sin/cos, fp32 pi
+// sites.  Same sampling decisions and estimator; values differ from EXACT mode
+// at the 1e-7 relative level per operation.
 #include <hip/hip_runtime.h>
 
 #include "ptk_dev.h"
 
 #define PTK_FAST 1
+#ifndef PTK_F_CONTRACT
+#define PTK_F_CONTRACT 0   // see render_kernel.inc
+#endif
+#if PTK_F_CONTRACT
 #pragma clang fp contract(fast)
+#else
+#pragma clang fp contract(off)
+#endif
 #include "render_kernel.inc"
 
 hipError_t ptk_launch_render_fast(const RenderArgs& a, int max_depth, bool features,

@@ -323,14 +323,15 @@ def test_post_process_matches_the_display_transform(ctx, oracle):
 
 
 @pytest.mark.parametrize("name,mean_tol", [("cornell_crystal", 2e-3), ("MultiLightGlass", 2e-3),
-                                           ("cornell", 2e-3), ("Box_Grid", 2e-2)])
+                                           ("cornell", 2e-3), ("Box_Grid", 5e-3)])
 def test_fast_math_is_statistically_equivalent(ctx, name, mean_tol):
-    """PTK_MATH_FAST (reciprocal slabs, rsq, hardware sin/cos, FMA) follows different paths
+    """PTK_MATH_FAST (reciprocal slabs, rsq, hardware sin/cos) follows different paths
     sample by sample, so it is held to the RMSE criterion: against a 4096-spp exact render,
-    256 fast samples have the exact mode's relative MSE (within 5 %; 25 % on Box_Grid) and the
-    image mean agrees within 0.2 % -- except on Box_Grid, whose many rotated boxes expose a
-    +0.8 % bias of the fast slabs (bounded here at 2 %), which is why fast mode is not the
-    default and not the benchmarked mode."""
+    256 fast samples have the exact mode's relative MSE (within 5 %; 10 % on Box_Grid) and the
+    image mean agrees within 0.2 % -- except on Box_Grid, where the reciprocal slab quotients
+    shift hit points enough to change how often grazing rays re-hit their own surface: +0.14 %
+    on the mean (bounded here at 0.5 %), which is why fast mode is not the default and not
+    the benchmarked mode."""
     import ptk
     W, H = 240, 135
     raw, _, _ = ptk.scene_constants(scene_path(name), W, H, 4, 0.005, False)
@@ -352,5 +353,5 @@ def test_fast_math_is_statistically_equivalent(ctx, name, mean_tol):
     m_ref = np.nanmean(ref)
     assert abs(out[ptk.MATH_EXACT][0] / m_ref - 1.0) < 2e-3
     assert abs(out[ptk.MATH_FAST][0] / m_ref - 1.0) < mean_tol
-    mse_tol = 0.25 if name == "Box_Grid" else 0.05
+    mse_tol = 0.10 if name == "Box_Grid" else 0.05
     assert abs(out[ptk.MATH_FAST][1] / out[ptk.MATH_EXACT][1] - 1.0) < mse_tol
