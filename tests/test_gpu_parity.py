@@ -355,3 +355,55 @@ def test_fast_math_is_statistically_equivalent(ctx, name, mean_tol):
     assert abs(out[ptk.MATH_FAST][0] / m_ref - 1.0) < mean_tol
     mse_tol = 0.10 if name == "Box_Grid" else 0.05
     assert abs(out[ptk.MATH_FAST][1] / out[ptk.MATH_EXACT][1] - 1.0) < mse_tol
+
+
+def test_full_tables_fifty_shapes_fifty_materials(ctx, oracle):
+    """The POD's limits (headers/GLOBALS.h:87-89): 50 shapes (25 boxes, most rotated, some flat,
+    and 25 spheres: 425 of the 450 attributes), 50 materials of all four kinds, some blurred,
+    10 important shapes, depth 12.  Same bar as the scene files: >= 98 % of pixels within 1e-4
+    after two samples with the reference seeds."""
+    import ptk
+    O = oracle
+    rng = np.random.default_rng(2024)
+    sc = O.load_scene(scene_path("cornell"))
+    c = O.build_constants(sc, 48, 32, 12, 0.005, True)
+    for m in range(50):
+        kind = m % 4
+        col = rng.uniform(0.2, 1.0, 3) * (4.0 if kind == 1 else 1.0)
+        blur = 0.05 if (kind >= 2 and m % 3 == 0) else 0.0
+        for k, v in enumerate((*col, blur, 1.5, float(kind))):
+            c.mats[m][k] = v
+    off = 0
+    for s in range(50):
+        pos = rng.uniform(-6, 6, 3) + np.array([0.0, 0.0, 14.0])
+        if s < 25:
+            half = rng.uniform(0.3, 1.2, 3)
+            if s % 5 == 0:
+                half[s % 3] = 0.0                       # flat
+            q = rng.normal(size=4) if s % 4 else np.array([1.0, 0, 0, 0])
+            q /= np.linalg.norm(q)
+            attrs = (*pos, *(pos - half), *(pos + half), *q)
+            c.shapes[s][0] = 1
+        else:
+            attrs = (*pos, rng.uniform(0.3, 1.0))
+            c.shapes[s][0] = 0
+        c.shapes[s][1] = s
+        c.shapes[s][2] = off
+        for k, v in enumerate(attrs):
+            c.attrs[off + k] = v
+        off += len(attrs)
+    assert off == 425
+    c.num_shapes = 50
+    c.num_imp = 10
+    for k in range(10):
+        c.imp[k] = 5 * k + 1 if k < 5 else 25 + 5 * (k - 5)   # five boxes, five spheres
+    acc = O.new_accumulators(48, 32)
+    n, glo, rays = O.render(c, acc, 2, 0, PIN_SEED, threads=4)
+    ctx.set_constants(c)
+    grays, gglo = ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    assert gglo == glo
+    planes = ctx.read_planes()
+    ok = _rel_ok(planes, acc, 1e-4).all(axis=0)
+    assert ok.mean() >= 0.98
+    # the oracle reports the last pass's bounce rays, the library the whole call's
+    assert abs(grays - 2 * rays) <= 0.02 * 2 * rays
