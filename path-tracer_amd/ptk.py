@@ -51,6 +51,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PtkError("libptk.so not found at %s: build it with `make -C path-tracer_amd` "
                        "(there is no CPU fallback)" % LIB_PATH)
+    # PyTorch wheels bundle their own HIP runtime under the same soname as the system's.
+    # Whichever copy a process loads first serves every later user, and torch finds no GPU
+    # through the system copy: when torch is present it must be loaded before libptk.so.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     fp = C.POINTER(C.c_float)
     vp = C.c_void_p
