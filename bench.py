@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--math", choices=["exact", "fast"], default="exact")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo rehearses the multi-rank path with several ranks on one GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-rank exchange path even with one rank (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denoise-probe", action="store_true")
     args = ap.parse_args()
@@ -198,8 +200,10 @@ def main():
     gpu = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     device = torch.device("cuda", gpu)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -212,8 +216,8 @@ def main():
     ctx.set_constants(raw)
     ctx.set_math_mode(ptk.MATH_FAST if args.math == "fast" else ptk.MATH_EXACT)
     ctx.set_stream_id(rank)
-    planes = multigpu.device_planes(ctx, device) if world > 1 else None
-    frame = torch.empty((3, W * H), dtype=torch.float32, device=device) if world > 1 else None
+    planes = multigpu.device_planes(ctx, device) if use_dist else None
+    frame = torch.empty((3, W * H), dtype=torch.float32, device=device) if use_dist else None
 
     spp = args.spp_per_step
     kernel_ms = []
@@ -224,7 +228,7 @@ def main():
         t = ctx.timing()
         kernel_ms.append(t.render_ms)
         kernel_rays.append(t.render_rays)
-        if world > 1:
+        if use_dist:
             # per-frame accumulation exchange: sum of the colour planes over ranks
             frame.copy_(planes[0:3])
             # the next render (on the context's own stream) rewrites these planes: let the
@@ -235,7 +239,7 @@ def main():
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[gpu]) if args.backend == "nccl" else dist.barrier()
             torch.cuda.synchronize()
 
@@ -249,7 +253,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         multigpu.all_reduce_(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -267,7 +271,7 @@ def main():
                         "maxDepth %d, device counter seeds, math=%s" % (
                             args.scene, W, H, spp, args.steps, args.depth, args.math),
             "samples_per_step_per_gpu": W * H * spp,
-            "exchange": "all-reduce of 3 colour planes per step" if world > 1 else "none",
+            "exchange": "all-reduce of 3 colour planes per step" if use_dist else "none",
         },
     }
     if rank == 0:
@@ -321,7 +325,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[gpu]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
