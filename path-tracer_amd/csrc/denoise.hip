@@ -62,58 +62,52 @@ DEV float div_by(float x, const Recip& R)
     return __builtin_amdgcn_div_fixupf(q, R.d, x);
 }
 
-// The reference's "median getter" procedure (DenoiserNN.cpp:190-256), literal,
-// on registers.  It is not a median.  In both passes the comparison with m[0]
-// has no effect (neither of its branches does anything for k == 0), so the
-// scan starts at k == 1.
+// The reference's "median getter" procedure (DenoiserNN.cpp:190-256).  It is
+// not a median: each pass pushes the nine values through a five-slot array
+// with the rules below, and slot 0 is the answer.  The reference scans
+// k = 1..4 and stops at the first k with !(v > m[k]) (the comparison with m[0]
+// has no effect in either pass).  Written here as selects on five registers:
+// the comparisons all use the array as it was before the insertion, exactly as
+// the scan does, because the scan only writes at the step where it stops.
+//   pass 1: stop at k -> m[k-1] = v;           never stopped -> m[0..3] = m[4], m[4] = v
+//   pass 2: stop at k -> m[0..k-1] = m[k], m[k] = v;  never stopped -> the same as k = 4
 #pragma clang fp contract(off)
-DEV void mg_insert_pass1(float v, float (&m)[5])
+struct Slots { float m0, m1, m2, m3, m4; };
+DEV void mg_insert_pass1(float v, Slots& s)
 {
-    bool done = false;
-#pragma unroll
-    for (int k = 1; k < 5; k++) {
-        if (!done) {
-            if (v > m[k]) {
-                if (k == 4) { float t = m[4]; m[3] = t; m[2] = t; m[1] = t; m[0] = t; m[4] = v; }
-            } else {
-                m[k - 1] = v;
-                done = true;
-            }
-        }
-    }
+    const bool g1 = v > s.m1, g2 = v > s.m2, g3 = v > s.m3, g4 = v > s.m4;
+    const bool a2 = g1 && g2, a3 = a2 && g3, a4 = a3 && g4;
+    const float m4 = s.m4;
+    s.m0 = a4 ? m4 : (g1 ? s.m0 : v);
+    s.m1 = a4 ? m4 : ((g1 && !g2) ? v : s.m1);
+    s.m2 = a4 ? m4 : ((a2 && !g3) ? v : s.m2);
+    s.m3 = a4 ? m4 : ((a3 && !g4) ? v : s.m3);
+    s.m4 = a4 ? v : m4;
 }
-DEV void mg_insert_pass2(float v, float (&m)[5])
+DEV void mg_insert_pass2(float v, Slots& s)
 {
-    bool done = false;
-#pragma unroll
-    for (int k = 1; k < 5; k++) {
-        if (!done) {
-            if (v > m[k]) {
-                if (k == 4) { float t = m[4]; m[3] = t; m[2] = t; m[1] = t; m[0] = t; m[4] = v; }
-            } else {
-                float t = m[k];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (q < k) m[q] = t;
-                m[k] = v;
-                done = true;
-            }
-        }
-    }
+    const bool g1 = v > s.m1, g2 = v > s.m2, g3 = v > s.m3;
+    const bool c1 = !g1, c2 = g1 && !g2, a2 = g1 && g2, c3 = a2 && !g3, c4 = a2 && g3;
+    const float fill = c1 ? s.m1 : (c2 ? s.m2 : (c3 ? s.m3 : s.m4));
+    const float m2 = s.m2, m3 = s.m3;
+    s.m0 = fill;
+    s.m1 = c1 ? v : fill;
+    s.m2 = c1 ? m2 : (c2 ? v : fill);
+    s.m3 = (c1 || c2) ? m3 : (c3 ? v : fill);
+    s.m4 = c4 ? v : s.m4;
 }
 DEV float mad_procedure(float (&v)[9])
 {
-    float m[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    Slots s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < 9; i++) mg_insert_pass1(v[i], m);
-    float m0 = m[0];
+    for (int i = 0; i < 9; i++) mg_insert_pass1(v[i], s);
+    const float m0 = s.m0;
 #pragma unroll
     for (int i = 0; i < 9; i++) v[i] = __builtin_fabsf(v[i] - m0);
+    s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 5; k++) m[k] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 9; i++) mg_insert_pass2(v[i], m);
-    return m[0];
+    for (int i = 0; i < 9; i++) mg_insert_pass2(v[i], s);
+    return s.m0;
 }
 
 // Primary feature of one pixel (DenoiserNN.cpp:16-36): three separate
