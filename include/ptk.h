@@ -125,6 +125,56 @@ const char* ptk_last_error(void);
 int ptk_set_constants(ptk_ctx* ctx, const void* constants, size_t nbytes,
                       int want_denoise_features);
 
+/* Scene description without the POD's fixed limits (the reference caps a scene
+ * at 50 shapes / 450 attribute floats / 50 materials / 10 important shapes,
+ * headers/GLOBALS.h:80-94).  Same fields and meanings as ptk_constants, with
+ * the per-shape tables as arrays of any length; every shape owns 13 attribute
+ * floats in the POD's order (sphere: centre, r, 9 unused; box: centre, lo, hi,
+ * quaternion w,x,y,z). */
+typedef struct ptk_scene_desc {
+    float cam_pos[3], cam_forward[3], cam_right[3], cam_up[3];
+    float rand_samp;
+    int32_t max_depth;
+    int32_t res_v, res_h;
+    float max_angle_v, max_angle_h, focal_length;
+    int32_t num_shapes;            /* 0 .. PTK_SCENE_MAX_SHAPES */
+    int32_t num_mats;              /* 1 .. PTK_SCENE_MAX_MATS */
+    int32_t num_important_shapes;  /* 0 .. num_shapes */
+    int32_t flags;                 /* PTK_SCENE_* */
+    const int32_t* shape_type;     /* [num_shapes] 0 sphere / 1 box */
+    const int32_t* shape_mat;      /* [num_shapes] material index */
+    const float* shape_attrs;      /* [num_shapes][13] */
+    const float* mat_list;         /* [num_mats][6] r,g,b, blur, refractive index, type 0..3 */
+    const uint32_t* important_shapes; /* [num_important_shapes] */
+} ptk_scene_desc;
+#define PTK_SCENE_MAX_SHAPES (1 << 24)
+#define PTK_SCENE_MAX_MATS 32767
+#define PTK_SCENE_ATTRS 13
+/* Give every node of the hierarchy unbounded extents, so each ray tests every
+ * shape: the same kernels with nothing culled (a checking aid). */
+#define PTK_SCENE_VISIT_ALL 1
+
+typedef struct ptk_scene_stats {
+    int32_t num_shapes, nodes, leaves, depth;
+    double build_ms;      /* host time spent compiling the shapes and building the hierarchy */
+    uint64_t device_bytes;
+} ptk_scene_stats;
+
+/* The scalable counterpart of ptk_set_constants (no counterpart in the
+ * reference, whose Renderers::UpdateConstants, Renderers.cpp:1051-1149, can
+ * only fill the fixed POD): the shapes are kept in HBM behind a bounding-volume
+ * hierarchy built here on the host, and ptk_render then traces through it.
+ * Every per-sample result is what the reference's index-order scans over the
+ * same shapes would give (closest hit with the lowest index among equal
+ * distances, Renderers.cpp:117-213; shadow rays stopped by the lowest-index
+ * opaque occluder and bent by refracting ones in index order, 490-668): the
+ * shapes are tested by the same routines and the hierarchy only skips shapes a
+ * ray cannot reach.  Box quaternions must be of unit length (within 1e-4).
+ * Everything else (planes, seeds, denoiser, post-process) is as after
+ * ptk_set_constants.  stats is optional. */
+int ptk_set_scene(ptk_ctx* ctx, const ptk_scene_desc* scene, int want_denoise_features,
+                  ptk_scene_stats* stats);
+
 /* The zeroing half of PT::RefreshScreen (PT.cpp:159-169): sampleCount = 0 and
  * all planes cleared. */
 int ptk_reset_accumulators(ptk_ctx* ctx);

@@ -37,6 +37,21 @@ class Constants(C.Structure):
 assert C.sizeof(Constants) == 3732
 
 
+class SceneDesc(C.Structure):
+    """orc_scene_desc (same layout as ptk_scene_desc of include/ptk.h)."""
+    _fields_ = [("cam_pos", C.c_float * 3), ("cam_forward", C.c_float * 3),
+                ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3),
+                ("rand_samp", C.c_float), ("max_depth", C.c_int32),
+                ("res_v", C.c_int32), ("res_h", C.c_int32),
+                ("max_angle_v", C.c_float), ("max_angle_h", C.c_float),
+                ("focal_length", C.c_float),
+                ("num_shapes", C.c_int32), ("num_mats", C.c_int32),
+                ("num_important_shapes", C.c_int32), ("flags", C.c_int32),
+                ("shape_type", C.POINTER(C.c_int32)), ("shape_mat", C.POINTER(C.c_int32)),
+                ("shape_attrs", C.POINTER(C.c_float)), ("mat_list", C.POINTER(C.c_float)),
+                ("important_shapes", C.POINTER(C.c_uint32))]
+
+
 class Sample(C.Structure):
     _fields_ = [
         ("xyz", C.c_float * 3), ("normal", C.c_float * 3), ("albedo1", C.c_float * 3),
@@ -101,6 +116,10 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(Constants), fp, C.c_int, C.POINTER(C.c_int),
                                  C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
         L.orc_render.restype = None
+        L.orc_render_scene.argtypes = [C.POINTER(SceneDesc), C.c_int, fp, C.c_int,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_int,
+                                       C.POINTER(C.c_uint64)]
+        L.orc_render_scene.restype = C.c_int
         L.orc_auto_exposure.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(C.c_double)]
         L.orc_auto_exposure.restype = C.c_float
@@ -188,6 +207,38 @@ def render(consts, acc, spp, sample_count, glo, threads=1):
     rays = C.c_uint64(0)
     lib().orc_render(C.byref(consts), _fp(acc), spp, C.byref(sc), st, threads, C.byref(rays))
     return sc.value, (int(st[0]), int(st[1])), int(rays.value)
+
+
+def render_scene(scene, acc, spp, sample_count, glo, want_features=False, threads=1):
+    """As render(), over a scene dict with tables of any length: cam_pos, cam_forward,
+    cam_right, cam_up, rand_samp, max_depth, res_v, res_h, max_angle_v, max_angle_h,
+    focal_length, shape_type [N], shape_mat [N], shape_attrs [N,13], mat_list [M,6],
+    important_shapes [K]."""
+    d = SceneDesc()
+    for k in ("cam_pos", "cam_forward", "cam_right", "cam_up"):
+        getattr(d, k)[:] = [float(v) for v in scene[k]]
+    for k in ("rand_samp", "max_angle_v", "max_angle_h", "focal_length"):
+        setattr(d, k, float(scene[k]))
+    for k in ("max_depth", "res_v", "res_h"):
+        setattr(d, k, int(scene[k]))
+    st = np.ascontiguousarray(scene["shape_type"], dtype=np.int32)
+    sm = np.ascontiguousarray(scene["shape_mat"], dtype=np.int32)
+    sa = np.ascontiguousarray(scene["shape_attrs"], dtype=np.float32).reshape(-1, 13)
+    ml = np.ascontiguousarray(scene["mat_list"], dtype=np.float32).reshape(-1, 6)
+    im = np.ascontiguousarray(scene["important_shapes"], dtype=np.uint32)
+    d.num_shapes, d.num_mats, d.num_important_shapes, d.flags = len(st), len(ml), len(im), 0
+    d.shape_type = st.ctypes.data_as(C.POINTER(C.c_int32))
+    d.shape_mat = sm.ctypes.data_as(C.POINTER(C.c_int32))
+    d.shape_attrs = sa.ctypes.data_as(C.POINTER(C.c_float))
+    d.mat_list = ml.ctypes.data_as(C.POINTER(C.c_float))
+    d.important_shapes = im.ctypes.data_as(C.POINTER(C.c_uint32))
+    sc = C.c_int(sample_count)
+    state = (C.c_uint64 * 2)(glo[0], glo[1])
+    rays = C.c_uint64(0)
+    rc = lib().orc_render_scene(C.byref(d), 1 if want_features else 0, _fp(acc), spp, C.byref(sc),
+                                state, threads, C.byref(rays))
+    assert rc == 0
+    return sc.value, (int(state[0]), int(state[1])), int(rays.value)
 
 
 def auto_exposure(acc, width, height, sample_count, formula=0):

@@ -268,9 +268,49 @@ static inline float cos_over_pi(float c)
 
 /* ------------------------------------------------------- one path sample */
 
-/* RenderFunc, Renderers.cpp:49-819. */
-void orc_render_sample(const orc_constants* c, int row, int col,
+/* The scene as the per-sample function reads it: the POD's fields, with the
+ * tables behind pointers so the same function serves scenes of any size. */
+typedef struct {
+    float cam_pos[3], cam_fwd[3], cam_right[3], cam_up[3];
+    float rand_samp;
+    int32_t num_shapes, max_depth, res_v, res_h;
+    float max_angle_v, max_angle_h, focal_length;
+    const int32_t (*shapes)[3];
+    const float* attrs;
+    const float (*mats)[6];
+    const uint32_t* imp;
+    uint32_t num_imp, want_features;
+} scene_view;
+
+static void view_of_constants(const orc_constants* k, scene_view* v)
+{
+    memcpy(v->cam_pos, k->cam_pos, sizeof v->cam_pos);
+    memcpy(v->cam_fwd, k->cam_fwd, sizeof v->cam_fwd);
+    memcpy(v->cam_right, k->cam_right, sizeof v->cam_right);
+    memcpy(v->cam_up, k->cam_up, sizeof v->cam_up);
+    v->rand_samp = k->rand_samp;
+    v->num_shapes = k->num_shapes; v->max_depth = k->max_depth;
+    v->res_v = k->res_v; v->res_h = k->res_h;
+    v->max_angle_v = k->max_angle_v; v->max_angle_h = k->max_angle_h;
+    v->focal_length = k->focal_length;
+    v->shapes = k->shapes; v->attrs = k->attrs; v->mats = k->mats; v->imp = k->imp;
+    v->num_imp = k->num_imp; v->want_features = k->want_features;
+}
+
+static void render_sample_view(const scene_view* c, int row, int col, int64_t s1, int64_t s2,
+                               orc_sample* out);
+
+void orc_render_sample(const orc_constants* k, int row, int col,
                        int64_t s1, int64_t s2, orc_sample* out)
+{
+    scene_view v;
+    view_of_constants(k, &v);
+    render_sample_view(&v, row, col, s1, s2, out);
+}
+
+/* RenderFunc, Renderers.cpp:49-819. */
+static void render_sample_view(const scene_view* c, int row, int col, int64_t s1, int64_t s2,
+                               orc_sample* out)
 {
     int64_t rng[2] = {s1, s2};
 #ifdef ORC_COUNT_OPS
@@ -656,7 +696,7 @@ void orc_render_sample(const orc_constants* c, int row, int col,
 
 /* One pixel's accumulate step, Renderers.cpp:845-888.  sample_count is the
  * count AFTER this pass's increment. */
-static void accumulate_pixel(const orc_constants* c, float* acc, size_t P, size_t i,
+static void accumulate_pixel(const scene_view* c, float* acc, size_t P, size_t i,
                              const orc_sample* s, int sample_count)
 {
     float n = (float)sample_count;
@@ -694,8 +734,53 @@ static void accumulate_pixel(const orc_constants* c, float* acc, size_t P, size_
     acc[(ORC_PL_SD + 5) * P + i] = acc[(ORC_PL_SDV + 15) * P + i] / n;
 }
 
-void orc_render(const orc_constants* c, float* acc, int spp, int* sample_count,
+static void render_view(const scene_view* c, float* acc, int spp, int* sample_count,
+                        uint64_t glo[2], int threads, uint64_t* rays_last_pass);
+
+void orc_render(const orc_constants* k, float* acc, int spp, int* sample_count,
                 uint64_t glo[2], int threads, uint64_t* rays_last_pass)
+{
+    scene_view v;
+    view_of_constants(k, &v);
+    render_view(&v, acc, spp, sample_count, glo, threads, rays_last_pass);
+}
+
+/* The reference's scans with the POD's size limits lifted: same per-sample
+ * function over tables of any length (13 attribute floats per shape). */
+int orc_render_scene(const orc_scene_desc* k, int want_features, float* acc, int spp,
+                     int* sample_count, uint64_t glo[2], int threads, uint64_t* rays_last_pass)
+{
+    if (k->num_shapes < 0) return -1;
+    int32_t (*shapes)[3] = malloc(sizeof(int32_t[3]) * (size_t)(k->num_shapes + 1));
+    if (!shapes) return -1;
+    for (int s = 0; s < k->num_shapes; s++) {
+        shapes[s][0] = k->shape_type[s];
+        shapes[s][1] = k->shape_mat[s];
+        shapes[s][2] = 13 * s;
+    }
+    scene_view v;
+    memcpy(v.cam_pos, k->cam_pos, sizeof v.cam_pos);
+    memcpy(v.cam_fwd, k->cam_forward, sizeof v.cam_fwd);
+    memcpy(v.cam_right, k->cam_right, sizeof v.cam_right);
+    memcpy(v.cam_up, k->cam_up, sizeof v.cam_up);
+    v.rand_samp = k->rand_samp;
+    v.num_shapes = k->num_shapes; v.max_depth = k->max_depth;
+    v.res_v = k->res_v; v.res_h = k->res_h;
+    v.max_angle_v = k->max_angle_v; v.max_angle_h = k->max_angle_h;
+    v.focal_length = k->focal_length;
+    v.shapes = (const int32_t (*)[3])shapes;
+    v.attrs = k->shape_attrs;
+    v.mats = (const float (*)[6])k->mat_list;
+    v.imp = k->important_shapes;
+    v.num_imp = (uint32_t)k->num_important_shapes;
+    v.want_features = want_features ? 1u : 0u;
+    render_view(&v, acc, spp, sample_count, glo, threads, rays_last_pass);
+    free(shapes);
+    return 0;
+}
+
+static void render_view(const scene_view* c, float* acc, int spp, int* sample_count,
+                        uint64_t glo[2], int threads, uint64_t* rays_last_pass)
 {
     int W = c->res_h, H = c->res_v;
     size_t P = (size_t)W * (size_t)H;
@@ -714,7 +799,7 @@ void orc_render(const orc_constants* c, float* acc, int spp, int* sample_count,
             for (int i = 0; i < W; i++) {
                 size_t idx = (size_t)j * W + i;
                 orc_sample s;
-                orc_render_sample(c, j, i, seeds[2 * idx], seeds[2 * idx + 1], &s);
+                render_sample_view(c, j, i, seeds[2 * idx], seeds[2 * idx + 1], &s);
                 accumulate_pixel(c, acc, P, idx, &s, sc);
                 rays += s.rays_sent;
             }

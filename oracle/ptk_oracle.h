@@ -94,6 +94,26 @@ void orc_render_sample(const orc_constants* c, int row, int col,
 void orc_render(const orc_constants* c, float* acc, int spp, int* sample_count,
                 uint64_t glo[2], int threads, uint64_t* rays_last_pass);
 
+/* Scene tables of any length, laid out as ptk_scene_desc (include/ptk.h). */
+typedef struct {
+    float cam_pos[3], cam_forward[3], cam_right[3], cam_up[3];
+    float rand_samp;
+    int32_t max_depth;
+    int32_t res_v, res_h;
+    float max_angle_v, max_angle_h, focal_length;
+    int32_t num_shapes, num_mats, num_important_shapes, flags;
+    const int32_t* shape_type;
+    const int32_t* shape_mat;
+    const float* shape_attrs;      /* 13 per shape */
+    const float* mat_list;         /* 6 per material */
+    const uint32_t* important_shapes;
+} orc_scene_desc;
+
+/* orc_render over such a scene: the reference's index-order scans with the
+ * POD's 50-shape limit lifted (nothing else changes).  Returns 0, or -1. */
+int orc_render_scene(const orc_scene_desc* scene, int want_features, float* acc, int spp,
+                     int* sample_count, uint64_t glo[2], int threads, uint64_t* rays_last_pass);
+
 /* formula 0: CPUAutoExp as written; 1: SkePUAutoExp as written; 2: 9.6 * mean. */
 float orc_auto_exposure(const float* acc, int width, int height, int sample_count,
                         int formula, double* raw_sum);

@@ -1,0 +1,176 @@
+// bvh_build.cpp -- binned surface-area-heuristic build, top down, with a switch
+// to median splits once a branch is deep enough that an unbalanced tree could
+// outgrow the kernels' traversal stack.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace {
+
+constexpr int BINS = 16;
+constexpr int SAH_DEPTH_LIMIT = 36;   // beyond this only median splits: depth <= 36 + log2(n)
+
+struct Box {
+    float lo[3], hi[3];
+    void clear()
+    {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::numeric_limits<float>::infinity();
+            hi[k] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const float* l, const float* h)
+    {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], l[k]);
+            hi[k] = std::max(hi[k], h[k]);
+        }
+    }
+    void grow(const Box& b) { grow(b.lo, b.hi); }
+    double half_area() const
+    {
+        double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+        if (!(x >= 0) || !(y >= 0) || !(z >= 0)) return 0.0;
+        return x * y + y * z + z * x;
+    }
+};
+
+struct Task { int node, slot, begin, end, depth; };
+
+}  // namespace
+
+bool ptk_build_bvh(int n, const float* lo, const float* hi, bool visit_all, BvhBuild& out)
+{
+    if (n < 0 || n > (1 << 24)) return false;
+    out.nodes.clear();
+    out.order.resize((size_t)n);
+    out.depth = 0;
+    out.leaves = 0;
+    for (int i = 0; i < n; i++) out.order[(size_t)i] = i;
+    std::vector<float> centre((size_t)n * 3);
+    for (size_t i = 0; i < (size_t)n * 3; i++) centre[i] = 0.5f * lo[i] + 0.5f * hi[i];
+
+    const float inf = std::numeric_limits<float>::infinity();
+    BvhNode blank;
+    for (int k = 0; k < 3; k++) blank.lo0[k] = blank.hi0[k] = blank.lo1[k] = blank.hi1[k] = 0.0f;
+    blank.child[0] = blank.child[1] = ~0;           // empty leaves
+    blank.min_index[0] = blank.min_index[1] = 0x7fffffff;
+    out.nodes.push_back(blank);
+
+    int32_t* order = out.order.data();
+    std::vector<Task> todo;
+    if (n <= PTK_BVH_LEAF_MAX) {
+        if (n > 0) todo.push_back({0, 0, 0, n, 1});
+    } else {
+        // the root's two children are made by splitting the whole range like any other
+        todo.push_back({-1, 0, 0, n, 0});
+    }
+
+    while (!todo.empty()) {
+        const Task t = todo.back();
+        todo.pop_back();
+        const int count = t.end - t.begin;
+        Box bounds, cbounds;
+        bounds.clear();
+        cbounds.clear();
+        int32_t min_index = 0x7fffffff;
+        for (int i = t.begin; i < t.end; i++) {
+            const size_t s = (size_t)order[i];
+            bounds.grow(lo + 3 * s, hi + 3 * s);
+            cbounds.grow(&centre[3 * s], &centre[3 * s]);
+            min_index = std::min(min_index, order[i]);
+        }
+
+        int self;   // the node whose children this range becomes, when it is split
+        if (t.node < 0) {
+            self = 0;
+        } else {
+            BvhNode& parent = out.nodes[(size_t)t.node];
+            float* plo = t.slot ? parent.lo1 : parent.lo0;
+            float* phi = t.slot ? parent.hi1 : parent.hi0;
+            for (int k = 0; k < 3; k++) {
+                plo[k] = visit_all ? -inf : bounds.lo[k];
+                phi[k] = visit_all ? inf : bounds.hi[k];
+            }
+            parent.min_index[t.slot] = min_index;
+            if (count <= PTK_BVH_LEAF_MAX) {
+                std::sort(order + t.begin, order + t.end);
+                parent.child[t.slot] = ~(t.begin * 8 + count);
+                out.leaves++;
+                out.depth = std::max(out.depth, t.depth);
+                continue;
+            }
+            self = (int)out.nodes.size();
+            out.nodes[(size_t)t.node].child[t.slot] = self;
+            out.nodes.push_back(blank);
+        }
+
+        // ---- choose the split
+        int mid = -1;
+        if (t.depth < SAH_DEPTH_LIMIT) {
+            double best_cost = std::numeric_limits<double>::infinity();
+            int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; axis++) {
+                const float c0 = cbounds.lo[axis], c1 = cbounds.hi[axis];
+                if (!(c1 > c0)) continue;
+                const double scale = BINS / ((double)c1 - c0);
+                Box bin_box[BINS];
+                int bin_n[BINS];
+                for (int b = 0; b < BINS; b++) { bin_box[b].clear(); bin_n[b] = 0; }
+                for (int i = t.begin; i < t.end; i++) {
+                    const size_t s = (size_t)order[i];
+                    int b = (int)(((double)centre[3 * s + axis] - c0) * scale);
+                    b = std::min(std::max(b, 0), BINS - 1);
+                    bin_box[b].grow(lo + 3 * s, hi + 3 * s);
+                    bin_n[b]++;
+                }
+                double right_area[BINS];
+                Box acc;
+                acc.clear();
+                for (int b = BINS - 1; b > 0; b--) {
+                    acc.grow(bin_box[b]);
+                    right_area[b] = acc.half_area();
+                }
+                acc.clear();
+                int left_n = 0;
+                for (int b = 0; b < BINS - 1; b++) {
+                    acc.grow(bin_box[b]);
+                    left_n += bin_n[b];
+                    if (left_n == 0 || left_n == count) continue;
+                    const double cost = acc.half_area() * left_n + right_area[b + 1] * (count - left_n);
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const float c0 = cbounds.lo[best_axis], c1 = cbounds.hi[best_axis];
+                const double scale = BINS / ((double)c1 - c0);
+                int32_t* m = std::partition(order + t.begin, order + t.end, [&](int32_t s) {
+                    int b = (int)(((double)centre[3 * (size_t)s + best_axis] - c0) * scale);
+                    b = std::min(std::max(b, 0), BINS - 1);
+                    return b <= best_bin;
+                });
+                mid = (int)(m - order);
+            }
+        }
+        if (mid <= t.begin || mid >= t.end) {
+            // median along the widest axis of the centres (or of the index order
+            // when all centres coincide)
+            int axis = 0;
+            float widest = -1.0f;
+            for (int k = 0; k < 3; k++) {
+                const float w = cbounds.hi[k] - cbounds.lo[k];
+                if (w > widest) { widest = w; axis = k; }
+            }
+            mid = t.begin + count / 2;
+            std::nth_element(order + t.begin, order + mid, order + t.end, [&](int32_t a, int32_t b) {
+                const float ca = centre[3 * (size_t)a + axis], cb = centre[3 * (size_t)b + axis];
+                return ca < cb || (ca == cb && a < b);
+            });
+        }
+        todo.push_back({self, 0, t.begin, mid, t.depth + 1});
+        todo.push_back({self, 1, mid, t.end, t.depth + 1});
+    }
+    return out.depth <= PTK_BVH_STACK - 2;
+}

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "bvh_build.h"
 #include "ptk_dev.h"
 
 static_assert(sizeof(ptk_constants) == PTK_CONSTANTS_BYTES, "ptk_constants must match the reference POD");
@@ -56,6 +57,12 @@ struct ptk_ctx {
     int math_mode = PTK_MATH_EXACT;
     uint64_t stream_id = 0;
     int sample_count = 0;
+
+    // scenes set through ptk_set_scene (device arrays, owned)
+    bool big_scene = false;
+    BigScene big = {};
+    void* big_alloc[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool has_blur = false;
 
     float* planes_d = nullptr;        // PTK_N_PLANES * pixels
     int64_t* seeds_d = nullptr;       // seed chunk
@@ -112,6 +119,33 @@ void free_image_buffers(ptk_ctx* c)
     c->staging_floats = 0;
 }
 
+void free_big_scene(ptk_ctx* c)
+{
+    for (void*& p : c->big_alloc) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    c->big = BigScene{};
+    c->big_scene = false;
+}
+
+// (Re)allocates the per-image buffers when the resolution changed.
+int ensure_image(ptk_ctx* c, int width, int height)
+{
+    if (width == c->width && height == c->height && c->planes_d) return PTK_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_image_buffers(c);
+    c->width = width;
+    c->height = height;
+    c->pixels = (size_t)width * (size_t)height;
+    const size_t P = c->pixels;
+    HIP_TRY(hipMalloc((void**)&c->planes_d, PTK_N_PLANES * P * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->variances_d, 7 * P * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->denoised_d, 3 * P * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->wcsum_d, P * sizeof(float)));
+    return PTK_OK;
+}
+
 int ensure_staging(ptk_ctx* c, size_t floats)
 {
     if (c->staging_floats >= floats) return PTK_OK;
@@ -159,6 +193,63 @@ void face_normal_host(const float q[4], const float n[3], float out[3])
     out[2] = qcc.z / len;
 }
 
+// One shape: the device record, the quaternion-only sums, the face normals and
+// the scan record (all zero on entry).  `at` is the shape's attribute run in the
+// POD's order: sphere centre, r; box centre, lo, hi, quaternion w,x,y,z.
+void compile_shape(int type, int mat, int mat_type, const float* at, DevShape& o, float rot[16],
+                   float face_normal[7][3], ScanRec& r)
+{
+    const float E = 0.00001f;
+    o.type = type;
+    o.mat = mat;
+    o.mat_type = mat_type;
+    o.flat_axis = -1;
+    o.c[0] = at[0]; o.c[1] = at[1]; o.c[2] = at[2];
+    if (type == 0) {
+        o.r = at[3];
+        o.rsq = at[3] * at[3];
+        o.q[0] = 1.0f;
+    } else {
+        for (int i = 0; i < 3; i++) { o.lo[i] = at[3 + i]; o.hi[i] = at[6 + i]; }
+        for (int i = 0; i < 4; i++) o.q[i] = at[9 + i];
+        o.rotated = (at[10] + at[11] + at[12] > E) ? 1 : 0;
+        {
+            // r = q in the first product, l = conj(q) in the second
+            // (Renderers.cpp:25-47); every entry is one fp32 operation
+            const float rw = o.q[0], rx = o.q[1], ry = o.q[2], rz = o.q[3];
+            const float lw = o.q[0], lx = -o.q[1], ly = -o.q[2], lz = -o.q[3];
+            float* t = rot;
+            t[0] = rx + ry; t[1] = rw + rz; t[2] = rw - rz; t[3] = rx - ry;
+            t[4] = ry - rz; t[5] = rx + rw; t[6] = ry + rz; t[7] = rw - rx;
+            t[8] = lz + lx; t[9] = lw - ly; t[10] = lw + ly; t[11] = lz - lx;
+            t[12] = lz - ly; t[13] = lx + lw; t[14] = lw - lx; t[15] = lz + ly;
+        }
+        for (int face = 0; face < 7; face++) {
+            float n[3] = {0.0f, 0.0f, 0.0f};
+            if (face > 0) n[(face - 1) / 2] = (face & 1) ? -1.0f : 1.0f;
+            face_normal_host(o.q, n, face_normal[face]);
+        }
+        for (int i = 2; i >= 0; i--)
+            if (std::fabs(o.lo[i] - o.hi[i]) < E) o.flat_axis = i;
+        for (int i = 0; i < 3; i++)
+            if (o.lo[i] == o.hi[i]) o.same_mask |= 1 << i;
+        // importance pdf area (Renderers.cpp:691-697)
+        float dx = at[3] - at[6], dy = at[4] - at[7], dz = at[5] - at[8];
+        float area = 0;
+        area += dx * dy * 2.0f;
+        area += dz * dy * 2.0f;
+        area += dx * dz * 2.0f;
+        o.area = area;
+    }
+    for (int i = 0; i < 3; i++) { r.c[i] = o.c[i]; r.lo[i] = o.lo[i]; r.hi[i] = o.hi[i]; }
+    r.rsq = o.rsq;
+    r.type = o.type;
+    r.rotated = o.rotated;
+    r.same_mask = o.same_mask;
+    r.mat_type = o.mat_type;
+    r.mat = o.mat;
+}
+
 int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
 {
     if (k.res_h <= 0 || k.res_v <= 0 || (int64_t)k.res_h * k.res_v > (int64_t)1 << 28)
@@ -198,7 +289,6 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
     }
     std::memcpy(d.mats, k.mat_list, sizeof d.mats);
 
-    const float E = 0.00001f;
     for (int s = 0; s < k.num_shapes; s++) {
         int type = k.shapes[s][0], mat = k.shapes[s][1], a = k.shapes[s][2];
         if (type != 0 && type != 1) return fail(PTK_ERR_ARG, "shape %d has type %d", s, type);
@@ -208,57 +298,8 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
         if (a < 0 || a + need > PTK_MAX_ATTRS)
             return fail(PTK_ERR_ARG, "shape %d attribute range [%d,%d) exceeds %d", s, a, a + need,
                         PTK_MAX_ATTRS);
-        const float* at = k.obj_attributes + a;
-        DevShape& o = d.shape[s];
-        o.type = type;
-        o.mat = mat;
-        o.mat_type = (int)k.mat_list[mat][5];
-        o.flat_axis = -1;
-        o.c[0] = at[0]; o.c[1] = at[1]; o.c[2] = at[2];
-        if (type == 0) {
-            o.r = at[3];
-            o.rsq = at[3] * at[3];
-            o.q[0] = 1.0f;
-        } else {
-            for (int i = 0; i < 3; i++) { o.lo[i] = at[3 + i]; o.hi[i] = at[6 + i]; }
-            for (int i = 0; i < 4; i++) o.q[i] = at[9 + i];
-            o.rotated = (at[10] + at[11] + at[12] > E) ? 1 : 0;
-            {
-                // r = q in the first product, l = conj(q) in the second
-                // (Renderers.cpp:25-47); every entry is one fp32 operation
-                const float rw = o.q[0], rx = o.q[1], ry = o.q[2], rz = o.q[3];
-                const float lw = o.q[0], lx = -o.q[1], ly = -o.q[2], lz = -o.q[3];
-                float* t = d.rot[s];
-                t[0] = rx + ry; t[1] = rw + rz; t[2] = rw - rz; t[3] = rx - ry;
-                t[4] = ry - rz; t[5] = rx + rw; t[6] = ry + rz; t[7] = rw - rx;
-                t[8] = lz + lx; t[9] = lw - ly; t[10] = lw + ly; t[11] = lz - lx;
-                t[12] = lz - ly; t[13] = lx + lw; t[14] = lw - lx; t[15] = lz + ly;
-            }
-            for (int face = 0; face < 7; face++) {
-                float n[3] = {0.0f, 0.0f, 0.0f};
-                if (face > 0) n[(face - 1) / 2] = (face & 1) ? -1.0f : 1.0f;
-                face_normal_host(o.q, n, d.face_normal[s][face]);
-            }
-            for (int i = 2; i >= 0; i--)
-                if (std::fabs(o.lo[i] - o.hi[i]) < E) o.flat_axis = i;
-            for (int i = 0; i < 3; i++)
-                if (o.lo[i] == o.hi[i]) o.same_mask |= 1 << i;
-            // importance pdf area (Renderers.cpp:691-697)
-            float dx = at[3] - at[6], dy = at[4] - at[7], dz = at[5] - at[8];
-            float area = 0;
-            area += dx * dy * 2.0f;
-            area += dz * dy * 2.0f;
-            area += dx * dz * 2.0f;
-            o.area = area;
-        }
-        ScanRec& r = d.scan[s];
-        for (int i = 0; i < 3; i++) { r.c[i] = o.c[i]; r.lo[i] = o.lo[i]; r.hi[i] = o.hi[i]; }
-        r.rsq = o.rsq;
-        r.type = o.type;
-        r.rotated = o.rotated;
-        r.same_mask = o.same_mask;
-        r.mat_type = o.mat_type;
-        r.mat = o.mat;
+        compile_shape(type, mat, (int)k.mat_list[mat][5], k.obj_attributes + a, d.shape[s], d.rot[s],
+                      d.face_normal[s], d.scan[s]);
     }
     return PTK_OK;
 }
@@ -321,6 +362,7 @@ int ptk_destroy(ptk_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_image_buffers(c);
+    free_big_scene(c);
     (void)hipFree(c->scene_d);
     (void)hipFree(c->rays_d);
     (void)hipFree(c->sum_d);
@@ -348,25 +390,212 @@ int ptk_set_constants(ptk_ctx* c, const void* constants, size_t nbytes, int want
     if (rc != PTK_OK) return rc;
     if ((rc = bind(c)) != PTK_OK) return rc;
 
-    if (k.res_h != c->width || k.res_v != c->height || !c->planes_d) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        free_image_buffers(c);
-        c->width = k.res_h;
-        c->height = k.res_v;
-        c->pixels = (size_t)k.res_h * (size_t)k.res_v;
-        const size_t P = c->pixels;
-        HIP_TRY(hipMalloc((void**)&c->planes_d, PTK_N_PLANES * P * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&c->variances_d, 7 * P * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&c->denoised_d, 3 * P * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&c->wcsum_d, P * sizeof(float)));
-    }
+    if ((rc = ensure_image(c, k.res_h, k.res_v)) != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_big_scene(c);
     c->host_scene = d;
     c->max_depth = k.max_depth;
+    c->features = feats != 0;
+    c->has_blur = false;
+    for (int i = 0; i < d.num_shapes; i++)
+        if (d.mats[d.shape[i].mat][3] > 0.0f) c->has_blur = true;
+    HIP_TRY(hipMemcpyAsync(c->scene_d, &c->host_scene, sizeof(DevScene), hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_scene = true;
+    return ptk_reset_accumulators(c);
+}
+
+int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features,
+                  ptk_scene_stats* stats)
+{
+    if (!c || !k) return fail(PTK_ERR_ARG, "ptk_set_scene: null argument");
+    if (k->res_h <= 0 || k->res_v <= 0 || (int64_t)k->res_h * k->res_v > (int64_t)1 << 28)
+        return fail(PTK_ERR_ARG, "resolution %dx%d out of range", k->res_h, k->res_v);
+    if (k->num_shapes < 0 || k->num_shapes > PTK_SCENE_MAX_SHAPES)
+        return fail(PTK_ERR_ARG, "num_shapes %d outside [0,%d]", k->num_shapes, PTK_SCENE_MAX_SHAPES);
+    if (k->num_mats < 1 || k->num_mats > PTK_SCENE_MAX_MATS)
+        return fail(PTK_ERR_ARG, "num_mats %d outside [1,%d]", k->num_mats, PTK_SCENE_MAX_MATS);
+    if (k->max_depth < 1 || k->max_depth > PTK_MAX_DEPTH)
+        return fail(PTK_ERR_ARG, "max_depth %d outside [1,%d]", k->max_depth, PTK_MAX_DEPTH);
+    if (k->num_important_shapes < 0 || k->num_important_shapes > k->num_shapes)
+        return fail(PTK_ERR_ARG, "num_important_shapes %d outside [0,%d]", k->num_important_shapes,
+                    k->num_shapes);
+    if (!k->mat_list || (k->num_shapes > 0 && (!k->shape_type || !k->shape_mat || !k->shape_attrs)) ||
+        (k->num_important_shapes > 0 && !k->important_shapes))
+        return fail(PTK_ERR_ARG, "ptk_set_scene: null table");
+    if (k->flags & ~PTK_SCENE_VISIT_ALL) return fail(PTK_ERR_ARG, "ptk_set_scene: flags %d", k->flags);
+
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int n = k->num_shapes;
+    const int feats = want_denoise_features > 0 ? 1 : 0;
+
+    DevScene d;
+    std::memset(&d, 0, sizeof d);
+    for (int i = 0; i < 3; i++) {
+        d.cam_pos[i] = k->cam_pos[i];
+        d.cam_fwd[i] = k->cam_forward[i];
+        d.cam_right[i] = k->cam_right[i];
+        d.cam_up[i] = k->cam_up[i];
+    }
+    d.rand_samp = k->rand_samp;
+    d.max_angle_v = k->max_angle_v;
+    d.max_angle_h = k->max_angle_h;
+    d.focal = k->focal_length;
+    d.num_shapes = n;
+    d.max_depth = k->max_depth;
+    d.res_v = k->res_v;
+    d.res_h = k->res_h;
+    d.num_imp = k->num_important_shapes;
+    d.want_features = feats;
+    d.inv_depth = 1.0f / (float)k->max_depth;
+    d.imp_boost = k->num_important_shapes > 1 ? (float)k->num_important_shapes : 1.0f;
+
+    std::vector<int32_t> imp((size_t)k->num_important_shapes + 1, 0);
+    for (int i = 0; i < k->num_important_shapes; i++) {
+        if (k->important_shapes[i] >= (uint32_t)n)
+            return fail(PTK_ERR_ARG, "important shape %d = %u is not a shape index", i,
+                        k->important_shapes[i]);
+        imp[(size_t)i] = (int32_t)k->important_shapes[i];
+    }
+
+    // ---- per-shape records, as for the POD
+    std::vector<DevShape> shapes((size_t)n + 1);
+    std::vector<float> rot(((size_t)n + 1) * 16, 0.0f);
+    std::vector<float> face_normal(((size_t)n + 1) * 21, 0.0f);
+    std::vector<ScanRec> scan((size_t)n + 1);
+    std::memset((void*)shapes.data(), 0, shapes.size() * sizeof(DevShape));
+    std::memset((void*)scan.data(), 0, scan.size() * sizeof(ScanRec));
+    bool has_blur = false, any_dielectric = false;
+    double extent = 1.0;
+    for (int i = 0; i < 3; i++) extent = std::max(extent, (double)std::fabs(k->cam_pos[i]));
+    for (int s = 0; s < n; s++) {
+        const int type = k->shape_type[s], mat = k->shape_mat[s];
+        const float* at = k->shape_attrs + (size_t)s * PTK_SCENE_ATTRS;
+        if (type != 0 && type != 1) return fail(PTK_ERR_ARG, "shape %d has type %d", s, type);
+        if (mat < 0 || mat >= k->num_mats) return fail(PTK_ERR_ARG, "shape %d has material %d", s, mat);
+        for (int i = 0; i < (type == 0 ? 4 : 13); i++)
+            if (!std::isfinite(at[i])) return fail(PTK_ERR_ARG, "shape %d attribute %d is not finite", s, i);
+        if (type == 1) {
+            double q2 = 0.0;
+            for (int i = 9; i < 13; i++) q2 += (double)at[i] * at[i];
+            if (std::fabs(q2 - 1.0) > 1e-4)
+                return fail(PTK_ERR_ARG, "shape %d: quaternion of squared length %g", s, q2);
+        }
+        const float* m = k->mat_list + (size_t)mat * 6;
+        compile_shape(type, mat, (int)m[5], at, shapes[(size_t)s], &rot[(size_t)s * 16],
+                      reinterpret_cast<float(*)[3]>(&face_normal[(size_t)s * 21]), scan[(size_t)s]);
+        has_blur = has_blur || m[3] > 0.0f;
+        any_dielectric = any_dielectric || (int)m[5] == 3;
+        for (int i = 0; i < (type == 0 ? 3 : 9); i++) extent = std::max(extent, (double)std::fabs(at[i]));
+        if (type == 0) extent = std::max(extent, (double)std::fabs(at[3]));
+    }
+
+    // ---- bounds.  A shape test accepts a ray only if the ray passes the shape
+    // within the test's rounding error, which grows with the distances involved
+    // (at most 2 sqrt(3) * extent): a few 1e-7 * extent for boxes (more after a
+    // quaternion rotation); for spheres the squared miss distance is a difference
+    // of two squares of order |centre - origin|^2 <= 12 extent^2 with ~6e-7
+    // relative error, so rays passing within sqrt(r^2 + 8e-6 * extent^2) of the
+    // centre may be accepted.  The slab test against a node adds a few ulps of the
+    // same distances.  The pad below is over ten times the sum of the linear terms.
+    const double pad = 2e-5 * extent;
+    std::vector<float> blo((size_t)n * 3 + 3), bhi((size_t)n * 3 + 3);
+    for (int s = 0; s < n; s++) {
+        const DevShape& o = shapes[(size_t)s];
+        double lo[3], hi[3];
+        if (o.type == 0) {
+            const double r = std::fabs((double)o.r);
+            const double reach = std::sqrt(r * r + 8e-6 * extent * extent) + pad;
+            for (int i = 0; i < 3; i++) { lo[i] = o.c[i] - reach; hi[i] = o.c[i] + reach; }
+        } else if (!o.rotated) {
+            for (int i = 0; i < 3; i++) {
+                lo[i] = std::min(o.lo[i], o.hi[i]) - pad;
+                hi[i] = std::max(o.lo[i], o.hi[i]) + pad;
+            }
+        } else {
+            // box space b = R (w - c) + c with R v = conj(q) v q; so w = q (b - c) conj(q) + c
+            const double w = o.q[0], x = o.q[1], y = o.q[2], z = o.q[3];
+            const double R[3][3] = {
+                {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+            for (int i = 0; i < 3; i++) { lo[i] = 1e300; hi[i] = -1e300; }
+            for (int corner = 0; corner < 8; corner++) {
+                double b[3];
+                for (int i = 0; i < 3; i++) b[i] = ((corner >> i) & 1 ? o.hi[i] : o.lo[i]) - (double)o.c[i];
+                for (int i = 0; i < 3; i++) {
+                    const double wv = R[i][0] * b[0] + R[i][1] * b[1] + R[i][2] * b[2] + o.c[i];
+                    lo[i] = std::min(lo[i], wv);
+                    hi[i] = std::max(hi[i], wv);
+                }
+            }
+            // the quaternion is of unit length only to 1e-4: scale slack on top of the pad
+            double span = 0.0;
+            for (int i = 0; i < 3; i++) span = std::max(span, hi[i] - lo[i]);
+            for (int i = 0; i < 3; i++) { lo[i] -= pad + 4e-4 * span; hi[i] += pad + 4e-4 * span; }
+        }
+        for (int i = 0; i < 3; i++) {
+            blo[(size_t)s * 3 + i] = std::nextafter((float)lo[i], -INFINITY);
+            bhi[(size_t)s * 3 + i] = std::nextafter((float)hi[i], INFINITY);
+        }
+    }
+    BvhBuild bvh;
+    if (!ptk_build_bvh(n, blo.data(), bhi.data(), (k->flags & PTK_SCENE_VISIT_ALL) != 0, bvh))
+        return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of depth %d exceeds the traversal stack",
+                    bvh.depth);
+    std::vector<ScanRec> leaf_recs((size_t)n + 1);
+    std::memset((void*)leaf_recs.data(), 0, leaf_recs.size() * sizeof(ScanRec));
+    for (int i = 0; i < n; i++) {
+        leaf_recs[(size_t)i] = scan[(size_t)bvh.order[(size_t)i]];
+        leaf_recs[(size_t)i].pad = bvh.order[(size_t)i];
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    if ((rc = ensure_image(c, k->res_h, k->res_v)) != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_big_scene(c);
+
+    const void* src[7] = {bvh.nodes.data(), leaf_recs.data(), rot.data(), face_normal.data(),
+                          shapes.data(), k->mat_list, imp.data()};
+    const size_t bytes[7] = {bvh.nodes.size() * sizeof(BvhNode), leaf_recs.size() * sizeof(ScanRec),
+                             rot.size() * sizeof(float), face_normal.size() * sizeof(float),
+                             shapes.size() * sizeof(DevShape), (size_t)k->num_mats * 6 * sizeof(float),
+                             imp.size() * sizeof(int32_t)};
+    uint64_t total = 0;
+    for (int i = 0; i < 7; i++) {
+        HIP_TRY(hipMalloc(&c->big_alloc[i], bytes[i]));
+        HIP_TRY(hipMemcpyAsync(c->big_alloc[i], src[i], bytes[i], hipMemcpyHostToDevice, c->stream));
+        total += bytes[i];
+    }
+    c->big.nodes = (const BvhNode*)c->big_alloc[0];
+    c->big.leaf_recs = (const ScanRec*)c->big_alloc[1];
+    c->big.rot = (const float*)c->big_alloc[2];
+    c->big.face_normal = (const float*)c->big_alloc[3];
+    c->big.shapes = (const float*)c->big_alloc[4];
+    c->big.mats = (const float*)c->big_alloc[5];
+    c->big.imp = (const int32_t*)c->big_alloc[6];
+    c->big.any_dielectric = any_dielectric ? 1 : 0;
+    c->big_scene = true;
+    c->has_blur = has_blur;
+    c->host_scene = d;
+    c->max_depth = k->max_depth;
     c->features = feats != 0;
     HIP_TRY(hipMemcpyAsync(c->scene_d, &c->host_scene, sizeof(DevScene), hipMemcpyHostToDevice,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = true;
+    if (stats) {
+        stats->num_shapes = n;
+        stats->nodes = (int32_t)bvh.nodes.size();
+        stats->leaves = bvh.leaves;
+        stats->depth = bvh.depth;
+        stats->build_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+        stats->device_bytes = total;
+    }
     return ptk_reset_accumulators(c);
 }
 
@@ -420,10 +649,12 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     a.stream_id = c->stream_id;
     a.width = c->width;
     a.height = c->height;
-    a.has_blur = 0;
-    for (int i = 0; i < c->host_scene.num_shapes; i++)
-        if (c->host_scene.mats[c->host_scene.shape[i].mat][3] > 0.0f) a.has_blur = 1;
-    auto launch = c->math_mode == PTK_MATH_FAST ? ptk_launch_render_fast : ptk_launch_render_exact;
+    a.has_blur = c->has_blur ? 1 : 0;
+    a.big = c->big;
+    auto launch = c->big_scene ? (c->math_mode == PTK_MATH_FAST ? ptk_launch_render_bvh_fast
+                                                                 : ptk_launch_render_bvh_exact)
+                               : (c->math_mode == PTK_MATH_FAST ? ptk_launch_render_fast
+                                                                 : ptk_launch_render_exact);
 
     double render_ms = 0.0, seed_ms = 0.0;
     if (seed_mode == PTK_SEED_COUNTER) {

@@ -66,6 +66,35 @@ struct DevScene {
     ScanRec scan[PTK_MAX_SHAPES + 1];   // one past the end so the look-ahead load is always valid
 };
 
+// ---- scenes beyond the POD's limits (ptk_set_scene): the shapes live in HBM
+// and rays find them through a bounding-volume hierarchy.
+//
+// A node holds the (padded) bounds of both children, so one 64-byte fetch
+// decides both.  child >= 0: node index.  child < 0: leaf, ~child =
+// first_record * 8 + count (count 0..4; an empty leaf is never entered usefully).
+// min_index is the lowest shape index below each child (shadow rays through
+// refracting shapes look for the lowest-index occluder).
+struct alignas(64) BvhNode {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t child[2];
+    int32_t min_index[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 16 dwords");
+#define PTK_BVH_LEAF_MAX 4
+#define PTK_BVH_STACK 64      // traversal stack entries per lane; the builder keeps trees shallower
+
+struct BigScene {
+    const BvhNode* nodes;        // node 0 is the root
+    const ScanRec* leaf_recs;    // scan records in leaf order; ScanRec::pad = shape index
+    const float* rot;            // [shape][16], as DevScene::rot
+    const float* face_normal;    // [shape][7][3], as DevScene::face_normal
+    const float* shapes;         // [shape] DevShape
+    const float* mats;           // [material][6]
+    const int32_t* imp;          // important shapes
+    int32_t any_dielectric;      // some shape's material is of type 3
+    int32_t pad;
+};
+
 struct RenderArgs {
     const DevScene* scene;   // device memory
     float* planes;           // PTK_N_PLANES * P floats
@@ -76,6 +105,7 @@ struct RenderArgs {
     int32_t spp;             // passes in this launch
     int32_t base_count;      // sampleCount before this launch
     int32_t has_blur;        // some shape's material has blur > 0
+    BigScene big;            // ptk_set_scene scenes only (render_bvh_*.hip)
 };
 
 // Launchers (defined next to their kernels).  All enqueue on `stream` and
@@ -84,6 +114,10 @@ hipError_t ptk_launch_render_exact(const RenderArgs& a, int max_depth, bool feat
                                    hipStream_t stream);
 hipError_t ptk_launch_render_fast(const RenderArgs& a, int max_depth, bool features,
                                   hipStream_t stream);
+hipError_t ptk_launch_render_bvh_exact(const RenderArgs& a, int max_depth, bool features,
+                                       hipStream_t stream);
+hipError_t ptk_launch_render_bvh_fast(const RenderArgs& a, int max_depth, bool features,
+                                      hipStream_t stream);
 
 // Luminance map + sum of planes 0..2.  sum_d holds PTK_EXPOSURE_SHARDS partial sums
 // PTK_EXPOSURE_SHARD_STRIDE doubles apart (all zero on entry); the total is their sum.

@@ -20,7 +20,7 @@
 hipError_t ptk_launch_render_fast(const RenderArgs& a, int max_depth, bool features,
                                   hipStream_t stream)
 {
-    if (max_depth <= 4) return launch_depth<4>(a, features, stream);
-    if (max_depth <= 8) return launch_depth<8>(a, features, stream);
-    return launch_depth<12>(a, features, stream);
+    if (max_depth <= 4) return launch_depth<4, false>(a, features, stream);
+    if (max_depth <= 8) return launch_depth<8, false>(a, features, stream);
+    return launch_depth<12, false>(a, features, stream);
 }

@@ -25,8 +25,10 @@ EXPORTS = [
     "ptk_read_planes", "ptk_write_planes", "ptk_planes_device", "ptk_get_sample_count",
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
     "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_save_target",
-    "ptk_set_target", "ptk_train_step", "ptk_timing", "ptk_synchronize",
+    "ptk_set_target", "ptk_train_step", "ptk_timing", "ptk_synchronize", "ptk_set_scene",
 ]
+SCENE_VISIT_ALL = 1
+SCENE_ATTRS = 13
 
 
 class PtkError(RuntimeError):
@@ -38,6 +40,76 @@ class Times(C.Structure):
                 ("features_ms", C.c_double), ("filter_ms", C.c_double), ("denoise_ms", C.c_double),
                 ("render_samples", C.c_uint64), ("render_rays", C.c_uint64),
                 ("post_ms", C.c_double), ("train_ms", C.c_double)]
+
+
+class SceneDesc(C.Structure):
+    """ptk_scene_desc."""
+    _fields_ = [("cam_pos", C.c_float * 3), ("cam_forward", C.c_float * 3),
+                ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3),
+                ("rand_samp", C.c_float), ("max_depth", C.c_int32),
+                ("res_v", C.c_int32), ("res_h", C.c_int32),
+                ("max_angle_v", C.c_float), ("max_angle_h", C.c_float),
+                ("focal_length", C.c_float),
+                ("num_shapes", C.c_int32), ("num_mats", C.c_int32),
+                ("num_important_shapes", C.c_int32), ("flags", C.c_int32),
+                ("shape_type", C.POINTER(C.c_int32)), ("shape_mat", C.POINTER(C.c_int32)),
+                ("shape_attrs", C.POINTER(C.c_float)), ("mat_list", C.POINTER(C.c_float)),
+                ("important_shapes", C.POINTER(C.c_uint32))]
+
+
+class SceneStats(C.Structure):
+    _fields_ = [("num_shapes", C.c_int32), ("nodes", C.c_int32), ("leaves", C.c_int32),
+                ("depth", C.c_int32), ("build_ms", C.c_double), ("device_bytes", C.c_uint64)]
+
+
+def scene_desc(scene, flags=0, cls=SceneDesc):
+    """Marshals a scene dict into a ptk_scene_desc.  Keys: cam_pos, cam_forward, cam_right,
+    cam_up, rand_samp, max_depth, res_v, res_h, max_angle_v, max_angle_h, focal_length,
+    shape_type [N], shape_mat [N], shape_attrs [N,13], mat_list [M,6], important_shapes [K].
+    Returns (struct, arrays the struct points into -- keep them alive)."""
+    d = cls()
+    for k in ("cam_pos", "cam_forward", "cam_right", "cam_up"):
+        getattr(d, k)[:] = [float(v) for v in scene[k]]
+    for k in ("rand_samp", "max_angle_v", "max_angle_h", "focal_length"):
+        setattr(d, k, float(scene[k]))
+    for k in ("max_depth", "res_v", "res_h"):
+        setattr(d, k, int(scene[k]))
+    st = np.ascontiguousarray(scene["shape_type"], dtype=np.int32)
+    sm = np.ascontiguousarray(scene["shape_mat"], dtype=np.int32)
+    sa = np.ascontiguousarray(scene["shape_attrs"], dtype=np.float32).reshape(-1, SCENE_ATTRS)
+    ml = np.ascontiguousarray(scene["mat_list"], dtype=np.float32).reshape(-1, 6)
+    im = np.ascontiguousarray(scene["important_shapes"], dtype=np.uint32)
+    assert len(st) == len(sm) == len(sa)
+    d.num_shapes, d.num_mats, d.num_important_shapes, d.flags = len(st), len(ml), len(im), flags
+    d.shape_type = st.ctypes.data_as(C.POINTER(C.c_int32))
+    d.shape_mat = sm.ctypes.data_as(C.POINTER(C.c_int32))
+    d.shape_attrs = sa.ctypes.data_as(C.POINTER(C.c_float))
+    d.mat_list = ml.ctypes.data_as(C.POINTER(C.c_float))
+    d.important_shapes = im.ctypes.data_as(C.POINTER(C.c_uint32))
+    return d, (st, sm, sa, ml, im)
+
+
+def scene_from_constants(constants):
+    """The 3732-byte scene POD as a scene dict (for ptk_set_scene)."""
+    raw = bytes(constants)
+    f = np.frombuffer(raw, dtype=np.float32)
+    i = np.frombuffer(raw, dtype=np.int32)
+    u = np.frombuffer(raw, dtype=np.uint32)
+    n = int(i[14])
+    shapes = i[21:21 + 150].reshape(50, 3)
+    attrs = f[171:171 + 450]
+    sa = np.zeros((n, SCENE_ATTRS), np.float32)
+    for s in range(n):
+        a = int(shapes[s, 2])
+        k = 4 if shapes[s, 0] == 0 else 13
+        sa[s, :k] = attrs[a:a + k]
+    num_imp = int(u[931])
+    return dict(cam_pos=f[0:3], cam_forward=f[3:6], cam_right=f[6:9], cam_up=f[9:12],
+                rand_samp=f[13], max_depth=int(i[15]), res_v=int(i[16]), res_h=int(i[17]),
+                max_angle_v=f[18], max_angle_h=f[19], focal_length=f[20],
+                shape_type=shapes[:n, 0].copy(), shape_mat=shapes[:n, 1].copy(), shape_attrs=sa,
+                mat_list=f[621:621 + 300].reshape(50, 6).copy(),
+                important_shapes=u[921:921 + num_imp].copy())
 
 
 _lib = None
@@ -84,6 +156,7 @@ def load():
     L.ptk_save_target.argtypes = [vp]
     L.ptk_set_target.argtypes = [vp, fp]
     L.ptk_train_step.argtypes = [vp, fp, fp, fp, C.c_int, C.c_float, fp]
+    L.ptk_set_scene.argtypes = [vp, C.POINTER(SceneDesc), C.c_int, C.POINTER(SceneStats)]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
     for name in EXPORTS:
@@ -132,6 +205,15 @@ class Context:
                                               want_features))
         hdr = np.frombuffer(raw, dtype=np.int32, count=20)
         self.height, self.width = int(hdr[16]), int(hdr[17])
+
+    def set_scene(self, scene, want_features=0, flags=0):
+        """scene: dict as for scene_desc().  Returns the hierarchy's statistics as a dict."""
+        d, keep = scene_desc(scene, flags)
+        st = SceneStats()
+        self._check(self._L.ptk_set_scene(self._h, C.byref(d), int(want_features), C.byref(st)))
+        del keep
+        self.height, self.width = int(d.res_v), int(d.res_h)
+        return {k: getattr(st, k) for k, _ in SceneStats._fields_}
 
     @property
     def pixels(self):

@@ -1,0 +1,170 @@
+"""GPU parity of the scalable scene path (ptk_set_scene: shapes in HBM behind a
+bounding-volume hierarchy) through the C ABI.
+
+What is checked, and to what bar:
+
+  * The reference's own scenes pushed through ptk_set_scene give the SAME BITS in
+    every plane as through ptk_set_constants (the fixed-size path whose parity
+    with the CPU checker test_gpu_parity.py establishes): the hierarchy changes
+    which shapes a ray is tested against, never a result.
+  * Scenes of hundreds to thousands of shapes give the same bits with the
+    hierarchy as with PTK_SCENE_VISIT_ALL (every ray tests every shape), with
+    and without refracting shapes and blur: nothing the index-order scan would
+    accept is culled.
+  * Against the CPU checker's index-order scan over the same tables
+    (orc_render_scene: the reference's per-sample function with the 50-shape
+    limit lifted -- "parity unpinned" beyond 50 shapes, since the reference
+    cannot hold such a scene): >= 99 % of pixels bit-identical per sample, the
+    same bar and for the same reason (libm rounding) as test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PIN_SEED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ptk
+    c = ptk.Context(0)
+    yield c
+    c.close()
+
+
+def _same(a, b):
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_crystal", "MultiLightGlass", "Box_Grid",
+                                  "blur_test", "bars3"])
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_reference_scenes_same_bits_as_fixed_size_path(ctx, name, math_mode):
+    import os
+    import ptk
+    g = np.load(os.path.join(GOLDEN, "render_%s_64x36.npz" % name))
+    raw = g["constants"].tobytes()
+    ctx.set_math_mode(math_mode)
+    ctx.set_constants(raw, want_features=1)
+    rays_a, glo_a = ctx.render(5, ptk.SEED_REFERENCE, PIN_SEED)
+    a = ctx.read_planes()
+    stats = ctx.set_scene(ptk.scene_from_constants(raw), want_features=1)
+    assert stats["num_shapes"] == np.frombuffer(raw, np.int32)[14]
+    rays_b, glo_b = ctx.render(5, ptk.SEED_REFERENCE, PIN_SEED)
+    b = ctx.read_planes()
+    ctx.set_math_mode(ptk.MATH_EXACT)
+    assert rays_a == rays_b and glo_a == glo_b
+    assert _same(a, b).all()
+
+
+@pytest.mark.parametrize("n,dielectric,blur,depth", [(300, True, False, 4), (300, True, True, 4),
+                                                     (2000, False, False, 4), (2000, True, False, 8),
+                                                     (5000, True, True, 12)])
+def test_hierarchy_culls_nothing_the_scan_would_accept(ctx, n, dielectric, blur, depth):
+    import ptk
+    import scenes
+    sc = scenes.random_scene(n, 96, 64, seed=n + depth, dielectric=dielectric, blur=blur,
+                             max_depth=depth)
+    stats = ctx.set_scene(sc, want_features=1)
+    assert stats["num_shapes"] == n and stats["depth"] <= 62 and stats["leaves"] >= n // 4
+    rays_a, _ = ctx.render(3, ptk.SEED_REFERENCE, PIN_SEED)
+    a = ctx.read_planes()
+    ctx.set_scene(sc, want_features=1, flags=ptk.SCENE_VISIT_ALL)
+    rays_b, _ = ctx.render(3, ptk.SEED_REFERENCE, PIN_SEED)
+    b = ctx.read_planes()
+    assert rays_a == rays_b
+    assert _same(a, b).all()
+    assert np.isfinite(a[0:3]).all() and a[0:3].mean() > 0
+
+
+@pytest.mark.parametrize("n,dielectric", [(120, True), (1500, True), (1500, False)])
+def test_against_index_order_scan_on_cpu(ctx, oracle, n, dielectric):
+    import ptk
+    import scenes
+    W, H = 64, 36
+    sc = scenes.random_scene(n, W, H, seed=7 * n, dielectric=dielectric)
+    ctx.set_scene(sc, want_features=1)
+    rays, glo = ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    gpu = ctx.read_planes()
+    acc = oracle.new_accumulators(W, H)
+    _, glo_o, rays_o = oracle.render_scene(sc, acc, 1, 0, PIN_SEED, want_features=True, threads=8)
+    assert glo == glo_o and rays == rays_o
+    same = _same(gpu[0:3], acc[0:3]).all(axis=0)
+    assert same.mean() >= 0.99
+    assert _same(gpu[3:16], acc[3:16]).all(axis=0).mean() >= 0.999
+    # four more samples: the accumulators agree where every sample agreed
+    ctx.render(4, ptk.SEED_REFERENCE, glo)
+    gpu = ctx.read_planes()
+    oracle.render_scene(sc, acc, 4, 1, glo_o, want_features=True, threads=8)
+    close = np.abs(gpu[0:3].astype(np.float64) - acc[0:3]) <= 1e-4 * np.abs(acc[0:3]) + 1e-7
+    assert close.all(axis=0).mean() >= 0.97
+    assert abs(gpu[0:3].mean() - acc[0:3].mean()) <= 2e-3 * acc[0:3].mean()
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 5])
+def test_tiny_scenes(ctx, oracle, n):
+    import ptk
+    import scenes
+    W, H = 32, 16
+    sc = scenes.random_scene(n, W, H, seed=11, lights=1)
+    stats = ctx.set_scene(sc)
+    assert stats["num_shapes"] == n
+    rays, _ = ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    gpu = ctx.read_planes(0, 3)
+    acc = oracle.new_accumulators(W, H)
+    oracle.render_scene(sc, acc, 2, 0, PIN_SEED, threads=1)
+    assert _same(gpu, acc[0:3]).all(axis=0).mean() >= 0.99
+    if n == 0:
+        assert rays == 2 * W * H     # every path is one ray into the sky
+
+
+def test_counter_seeds_and_statistics(ctx):
+    import ptk
+    import scenes
+    sc = scenes.grid_scene(12, 128, 72)
+    stats = ctx.set_scene(sc, want_features=1)
+    assert stats["nodes"] > 100 and stats["device_bytes"] > 0
+    ctx.render(4, ptk.SEED_COUNTER)
+    a = ctx.read_planes()
+    ctx.reset()
+    ctx.render(1, ptk.SEED_COUNTER)
+    ctx.render(3, ptk.SEED_COUNTER)
+    b = ctx.read_planes()
+    assert _same(a, b).all()      # split launches carry the running statistics
+    assert ctx.sample_count == 4
+    # the fixed-size path takes over again
+    import os
+    raw = np.load(os.path.join(GOLDEN, "render_cornell_64x36.npz"))["constants"].tobytes()
+    ctx.set_constants(raw)
+    ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    assert np.isfinite(ctx.read_planes(0, 3)).all()
+
+
+def test_bad_scenes_are_rejected(ctx):
+    import ptk
+    import scenes
+    sc = scenes.random_scene(40, 32, 16, seed=5)
+    bad = dict(sc)
+    bad["shape_mat"] = sc["shape_mat"].copy()
+    bad["shape_mat"][3] = 99
+    with pytest.raises(ptk.PtkError, match="material"):
+        ctx.set_scene(bad)
+    bad = dict(sc)
+    bad["important_shapes"] = np.asarray([40], np.uint32)
+    with pytest.raises(ptk.PtkError, match="important"):
+        ctx.set_scene(bad)
+    bad = dict(sc)
+    bad["shape_attrs"] = sc["shape_attrs"].copy()
+    box = int(np.nonzero(sc["shape_type"] == 1)[0][0])
+    bad["shape_attrs"][box, 9:13] = [2.0, 0.0, 0.0, 0.0]
+    with pytest.raises(ptk.PtkError, match="quaternion"):
+        ctx.set_scene(bad)
+    bad["shape_attrs"][box, 9:13] = [1.0, 0.0, 0.0, 0.0]
+    bad["shape_attrs"][box, 0] = np.nan
+    with pytest.raises(ptk.PtkError, match="finite"):
+        ctx.set_scene(bad)
+    bad = dict(sc)
+    bad["max_depth"] = 13
+    with pytest.raises(ptk.PtkError, match="max_depth"):
+        ctx.set_scene(bad)
