@@ -44,6 +44,10 @@ struct Task { int node, slot, begin, end, depth; };
 bool ptk_build_bvh(int n, const float* lo, const float* hi, bool visit_all, BvhBuild& out)
 {
     if (n < 0 || n > (1 << 24)) return false;
+    // One shape per leaf: a shape test costs two to four node visits, and a lane
+    // testing a shape its neighbours do not idles them (grid of 97 k shapes: 384 /
+    // 373 / 359 / 342 Msamples/s at 1 / 2 / 3 / 4 shapes per leaf).
+    const int leaf_max = PTK_BVH_LEAF_SIZE;
     out.nodes.clear();
     out.order.resize((size_t)n);
     out.depth = 0;
@@ -61,7 +65,7 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, bool visit_all, BvhB
 
     int32_t* order = out.order.data();
     std::vector<Task> todo;
-    if (n <= PTK_BVH_LEAF_MAX) {
+    if (n <= leaf_max) {
         if (n > 0) todo.push_back({0, 0, 0, n, 1});
     } else {
         // the root's two children are made by splitting the whole range like any other
@@ -95,7 +99,7 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, bool visit_all, BvhB
                 phi[k] = visit_all ? inf : bounds.hi[k];
             }
             parent.min_index[t.slot] = min_index;
-            if (count <= PTK_BVH_LEAF_MAX) {
+            if (count <= leaf_max) {
                 std::sort(order + t.begin, order + t.end);
                 parent.child[t.slot] = ~(t.begin * 8 + count);
                 out.leaves++;

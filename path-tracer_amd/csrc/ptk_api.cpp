@@ -492,6 +492,9 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
         if (type == 0) extent = std::max(extent, (double)std::fabs(at[3]));
     }
 
+    if (extent > 1e6)
+        return fail(PTK_ERR_ARG, "ptk_set_scene: coordinates up to %g exceed 1e6", extent);
+
     // ---- bounds.  A shape test accepts a ray only if the ray passes the shape
     // within the test's rounding error, which grows with the distances involved
     // (at most 2 sqrt(3) * extent): a few 1e-7 * extent for boxes (more after a

@@ -80,7 +80,8 @@ struct alignas(64) BvhNode {
     int32_t min_index[2];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 16 dwords");
-#define PTK_BVH_LEAF_MAX 4
+#define PTK_BVH_LEAF_MAX 4       // what the leaf code can express
+#define PTK_BVH_LEAF_SIZE 1      // what the builder makes
 #define PTK_BVH_STACK 64      // traversal stack entries per lane; the builder keeps trees shallower
 
 struct BigScene {
