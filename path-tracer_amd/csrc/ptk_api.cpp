@@ -544,16 +544,22 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
             bhi[(size_t)s * 3 + i] = std::nextafter((float)hi[i], INFINITY);
         }
     }
+    std::vector<uint8_t> kind((size_t)n + 1, 0);
+    std::vector<LeafRec> recs((size_t)n + 1);
+    std::memset((void*)recs.data(), 0, recs.size() * sizeof(LeafRec));
+    for (int s = 0; s < n; s++) {
+        const DevShape& o = shapes[(size_t)s];
+        kind[(size_t)s] = o.type == 0 ? 0 : (o.rotated ? 2 : 1);
+        LeafRec& r = recs[(size_t)s];
+        for (int i = 0; i < 3; i++) { r.c[i] = o.c[i]; r.lo[i] = o.lo[i]; }
+        r.rsq = o.rsq;
+        r.hi_x = o.hi[0]; r.hi_y = o.hi[1]; r.hi_z = o.hi[2];
+        r.same_mask = o.same_mask;
+    }
     BvhBuild bvh;
-    if (!ptk_build_bvh(n, blo.data(), bhi.data(), (k->flags & PTK_SCENE_VISIT_ALL) != 0, bvh))
+    if (!ptk_build_bvh(n, blo.data(), bhi.data(), kind.data(), bvh))
         return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of depth %d exceeds the traversal stack",
                     bvh.depth);
-    std::vector<ScanRec> leaf_recs((size_t)n + 1);
-    std::memset((void*)leaf_recs.data(), 0, leaf_recs.size() * sizeof(ScanRec));
-    for (int i = 0; i < n; i++) {
-        leaf_recs[(size_t)i] = scan[(size_t)bvh.order[(size_t)i]];
-        leaf_recs[(size_t)i].pad = bvh.order[(size_t)i];
-    }
     clock_gettime(CLOCK_MONOTONIC, &t1);
 
     int rc = bind(c);
@@ -562,9 +568,9 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_big_scene(c);
 
-    const void* src[7] = {bvh.nodes.data(), leaf_recs.data(), rot.data(), face_normal.data(),
+    const void* src[7] = {bvh.nodes.data(), recs.data(), rot.data(), face_normal.data(),
                           shapes.data(), k->mat_list, imp.data()};
-    const size_t bytes[7] = {bvh.nodes.size() * sizeof(BvhNode), leaf_recs.size() * sizeof(ScanRec),
+    const size_t bytes[7] = {bvh.nodes.size() * sizeof(BvhNode), recs.size() * sizeof(LeafRec),
                              rot.size() * sizeof(float), face_normal.size() * sizeof(float),
                              shapes.size() * sizeof(DevShape), (size_t)k->num_mats * 6 * sizeof(float),
                              imp.size() * sizeof(int32_t)};
@@ -575,13 +581,18 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
         total += bytes[i];
     }
     c->big.nodes = (const BvhNode*)c->big_alloc[0];
-    c->big.leaf_recs = (const ScanRec*)c->big_alloc[1];
+    c->big.recs = (const LeafRec*)c->big_alloc[1];
     c->big.rot = (const float*)c->big_alloc[2];
     c->big.face_normal = (const float*)c->big_alloc[3];
     c->big.shapes = (const float*)c->big_alloc[4];
     c->big.mats = (const float*)c->big_alloc[5];
     c->big.imp = (const int32_t*)c->big_alloc[6];
+    for (int i = 0; i < 3; i++) {
+        c->big.grid_base[i] = bvh.grid_base[i];
+        c->big.grid_scale[i] = bvh.grid_scale[i];
+    }
     c->big.any_dielectric = any_dielectric ? 1 : 0;
+    c->big.visit_all = (k->flags & PTK_SCENE_VISIT_ALL) ? 1 : 0;
     c->big_scene = true;
     c->has_blur = has_blur;
     c->host_scene = d;

@@ -69,31 +69,38 @@ struct DevScene {
 // ---- scenes beyond the POD's limits (ptk_set_scene): the shapes live in HBM
 // and rays find them through a bounding-volume hierarchy.
 //
-// A node holds the (padded) bounds of both children, so one 64-byte fetch
-// decides both.  child >= 0: node index.  child < 0: leaf, ~child =
-// first_record * 8 + count (count 0..4; an empty leaf is never entered usefully).
-// min_index is the lowest shape index below each child (shadow rays through
-// refracting shapes look for the lowest-index occluder).
-struct alignas(64) BvhNode {
-    float lo0[3], hi0[3], lo1[3], hi1[3];
+// A node holds the (padded) bounds of both children, so one 32-byte fetch
+// decides both: twelve 16-bit coordinates on a grid spanning the scene
+// (BigScene::grid_base + q * grid_scale), lower bounds rounded down and upper
+// bounds up.  child >= 0: node index.  child < 0: a leaf of one shape,
+// ~child = shape * 4 + kind (0 sphere, 1 box, 2 rotated box, 3 nothing).
+struct alignas(32) BvhNode {
+    uint16_t q[12];      // child 0 lo xyz, hi xyz; child 1 lo xyz, hi xyz
     int32_t child[2];
-    int32_t min_index[2];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 16 dwords");
-#define PTK_BVH_LEAF_MAX 4       // what the leaf code can express
-#define PTK_BVH_LEAF_SIZE 1      // what the builder makes
+static_assert(sizeof(BvhNode) == 32, "BvhNode must be 8 dwords");
 #define PTK_BVH_STACK 64      // traversal stack entries per lane; the builder keeps trees shallower
+
+// What a shape test reads, by shape index; a sphere needs the first 16 bytes only.
+struct alignas(16) LeafRec {
+    float c[3], rsq;
+    float lo[3], hi_x;
+    float hi_y, hi_z;
+    int32_t same_mask, pad;
+};
+static_assert(sizeof(LeafRec) == 48, "LeafRec must be 12 dwords");
 
 struct BigScene {
     const BvhNode* nodes;        // node 0 is the root
-    const ScanRec* leaf_recs;    // scan records in leaf order; ScanRec::pad = shape index
+    const LeafRec* recs;         // [shape]
     const float* rot;            // [shape][16], as DevScene::rot
     const float* face_normal;    // [shape][7][3], as DevScene::face_normal
     const float* shapes;         // [shape] DevShape
     const float* mats;           // [material][6]
     const int32_t* imp;          // important shapes
+    float grid_base[3], grid_scale[3];
     int32_t any_dielectric;      // some shape's material is of type 3
-    int32_t pad;
+    int32_t visit_all;           // every node test passes: each ray tests every shape
 };
 
 struct RenderArgs {
