@@ -171,6 +171,22 @@ def denoise_probe(ctx, W, H, depth):
     return out
 
 
+def hierarchy_probe(ctx, W, H):
+    """Scenes beyond the reference's 50-shape POD (ptk_set_scene): a synthetic grid of ~97 k
+    spheres and boxes behind the hierarchy, 8 spp, no features."""
+    import scenes
+    sc = scenes.grid_scene(46, W, H)
+    st = ctx.set_scene(sc)
+    ctx.render(2, ptk.SEED_COUNTER)
+    ctx.render(8, ptk.SEED_COUNTER)
+    t = ctx.timing()
+    return {"workload": "synthetic grid, %d shapes, %dx%d, 8 spp, maxDepth 4" % (st["num_shapes"], W, H),
+            "msamples_per_s": t.render_samples / t.render_ms / 1e3,
+            "mrays_per_s": t.render_rays / t.render_ms / 1e3,
+            "nodes": st["nodes"], "depth": st["depth"], "host_build_ms": st["build_ms"],
+            "device_mb": st["device_bytes"] / 1e6}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,6 +337,7 @@ def main():
         if world == 1:
             if not args.no_denoise_probe:
                 out["denoise"] = denoise_probe(ctx, W, H, args.depth)
+                out["scene_hierarchy"] = hierarchy_probe(ctx, W, H)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth)
         print(json.dumps(out), flush=True)

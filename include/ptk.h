@@ -175,6 +175,13 @@ typedef struct ptk_scene_stats {
 int ptk_set_scene(ptk_ctx* ctx, const ptk_scene_desc* scene, int want_denoise_features,
                   ptk_scene_stats* stats);
 
+/* The host half of ptk_set_scene without a context or a GPU: validates the
+ * description, compiles the shapes, builds the hierarchy and verifies it (every
+ * shape in exactly one leaf, every node's bounds holding the padded bounds of
+ * what lies beneath, depth within the kernels' traversal stack).  stats is
+ * optional (device_bytes is 0). */
+int ptk_check_scene(const ptk_scene_desc* scene, ptk_scene_stats* stats);
+
 /* The zeroing half of PT::RefreshScreen (PT.cpp:159-169): sampleCount = 0 and
  * all planes cleared. */
 int ptk_reset_accumulators(ptk_ctx* ctx);

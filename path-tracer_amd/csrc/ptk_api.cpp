@@ -406,10 +406,25 @@ int ptk_set_constants(ptk_ctx* c, const void* constants, size_t nbytes, int want
     return ptk_reset_accumulators(c);
 }
 
-int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features,
-                  ptk_scene_stats* stats)
+}  // extern "C"
+
+namespace {
+
+// Everything ptk_set_scene derives from a scene description on the host.
+struct HostBigScene {
+    DevScene d;
+    std::vector<int32_t> imp;
+    std::vector<DevShape> shapes;
+    std::vector<float> rot, face_normal;
+    std::vector<LeafRec> recs;
+    std::vector<float> blo, bhi;      // padded bounds per shape
+    BvhBuild bvh;
+    bool has_blur = false, any_dielectric = false;
+    double build_ms = 0.0;
+};
+
+int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBigScene& H)
 {
-    if (!c || !k) return fail(PTK_ERR_ARG, "ptk_set_scene: null argument");
     if (k->res_h <= 0 || k->res_v <= 0 || (int64_t)k->res_h * k->res_v > (int64_t)1 << 28)
         return fail(PTK_ERR_ARG, "resolution %dx%d out of range", k->res_h, k->res_v);
     if (k->num_shapes < 0 || k->num_shapes > PTK_SCENE_MAX_SHAPES)
@@ -431,7 +446,7 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     const int n = k->num_shapes;
     const int feats = want_denoise_features > 0 ? 1 : 0;
 
-    DevScene d;
+    DevScene& d = H.d;
     std::memset(&d, 0, sizeof d);
     for (int i = 0; i < 3; i++) {
         d.cam_pos[i] = k->cam_pos[i];
@@ -452,7 +467,8 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     d.inv_depth = 1.0f / (float)k->max_depth;
     d.imp_boost = k->num_important_shapes > 1 ? (float)k->num_important_shapes : 1.0f;
 
-    std::vector<int32_t> imp((size_t)k->num_important_shapes + 1, 0);
+    std::vector<int32_t>& imp = H.imp;
+    imp.assign((size_t)k->num_important_shapes + 1, 0);
     for (int i = 0; i < k->num_important_shapes; i++) {
         if (k->important_shapes[i] >= (uint32_t)n)
             return fail(PTK_ERR_ARG, "important shape %d = %u is not a shape index", i,
@@ -461,13 +477,18 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     }
 
     // ---- per-shape records, as for the POD
-    std::vector<DevShape> shapes((size_t)n + 1);
-    std::vector<float> rot(((size_t)n + 1) * 16, 0.0f);
-    std::vector<float> face_normal(((size_t)n + 1) * 21, 0.0f);
+    std::vector<DevShape>& shapes = H.shapes;
+    std::vector<float>& rot = H.rot;
+    std::vector<float>& face_normal = H.face_normal;
+    shapes.resize((size_t)n + 1);
+    rot.assign(((size_t)n + 1) * 16, 0.0f);
+    face_normal.assign(((size_t)n + 1) * 21, 0.0f);
     std::vector<ScanRec> scan((size_t)n + 1);
     std::memset((void*)shapes.data(), 0, shapes.size() * sizeof(DevShape));
     std::memset((void*)scan.data(), 0, scan.size() * sizeof(ScanRec));
-    bool has_blur = false, any_dielectric = false;
+    bool& has_blur = H.has_blur;
+    bool& any_dielectric = H.any_dielectric;
+    has_blur = any_dielectric = false;
     double extent = 1.0;
     for (int i = 0; i < 3; i++) extent = std::max(extent, (double)std::fabs(k->cam_pos[i]));
     for (int s = 0; s < n; s++) {
@@ -504,7 +525,10 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     // centre may be accepted.  The slab test against a node adds a few ulps of the
     // same distances.  The pad below is over ten times the sum of the linear terms.
     const double pad = 2e-5 * extent;
-    std::vector<float> blo((size_t)n * 3 + 3), bhi((size_t)n * 3 + 3);
+    std::vector<float>& blo = H.blo;
+    std::vector<float>& bhi = H.bhi;
+    blo.assign((size_t)n * 3 + 3, 0.0f);
+    bhi.assign((size_t)n * 3 + 3, 0.0f);
     for (int s = 0; s < n; s++) {
         const DevShape& o = shapes[(size_t)s];
         double lo[3], hi[3];
@@ -545,7 +569,8 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
         }
     }
     std::vector<uint8_t> kind((size_t)n + 1, 0);
-    std::vector<LeafRec> recs((size_t)n + 1);
+    std::vector<LeafRec>& recs = H.recs;
+    recs.resize((size_t)n + 1);
     std::memset((void*)recs.data(), 0, recs.size() * sizeof(LeafRec));
     for (int s = 0; s < n; s++) {
         const DevShape& o = shapes[(size_t)s];
@@ -556,14 +581,122 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
         r.hi_x = o.hi[0]; r.hi_y = o.hi[1]; r.hi_z = o.hi[2];
         r.same_mask = o.same_mask;
     }
-    BvhBuild bvh;
+    BvhBuild& bvh = H.bvh;
     if (!ptk_build_bvh(n, blo.data(), bhi.data(), kind.data(), bvh))
         return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of depth %d exceeds the traversal stack",
                     bvh.depth);
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    H.build_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    return PTK_OK;
+}
 
-    int rc = bind(c);
+void fill_scene_stats(const HostBigScene& H, uint64_t device_bytes, ptk_scene_stats* stats)
+{
+    if (!stats) return;
+    stats->num_shapes = H.d.num_shapes;
+    stats->nodes = (int32_t)H.bvh.nodes.size();
+    stats->leaves = H.bvh.leaves;
+    stats->depth = H.bvh.depth;
+    stats->build_ms = H.build_ms;
+    stats->device_bytes = device_bytes;
+}
+
+// Walks the tree below one child slot; returns false on any broken invariant:
+// a shape in two leaves, a leaf code of the wrong kind, or grid bounds that do
+// not contain the padded bounds of everything beneath them.
+bool check_subtree(const HostBigScene& H, int child, const uint16_t* q, std::vector<uint8_t>& seen,
+                   int depth, int& max_depth)
+{
+    // iterative, explicit stack of (child code, bounds it must fit in, depth)
+    struct Item { int child; double lo[3], hi[3]; int depth; };
+    std::vector<Item> todo;
+    Item first;
+    first.child = child;
+    first.depth = depth;
+    for (int k = 0; k < 3; k++) {
+        first.lo[k] = (double)H.bvh.grid_base[k] + (double)q[k] * H.bvh.grid_scale[k];
+        first.hi[k] = (double)H.bvh.grid_base[k] + (double)q[3 + k] * H.bvh.grid_scale[k];
+    }
+    todo.push_back(first);
+    const int n = H.d.num_shapes;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        max_depth = std::max(max_depth, it.depth);
+        if (it.child < 0) {
+            const int code = ~it.child;
+            if ((code & 3) == 3) continue;
+            const int s = code >> 2;
+            if (s < 0 || s >= n || seen[(size_t)s]) return false;
+            seen[(size_t)s] = 1;
+            const DevShape& o = H.shapes[(size_t)s];
+            const int kind = o.type == 0 ? 0 : (o.rotated ? 2 : 1);
+            if ((code & 3) != kind) return false;
+            for (int k = 0; k < 3; k++)
+                if (H.blo[(size_t)s * 3 + k] < it.lo[k] || H.bhi[(size_t)s * 3 + k] > it.hi[k]) return false;
+            continue;
+        }
+        if ((size_t)it.child >= H.bvh.nodes.size()) return false;
+        const BvhNode& nd = H.bvh.nodes[(size_t)it.child];
+        for (int c = 0; c < 2; c++) {
+            Item next;
+            next.child = nd.child[c];
+            next.depth = it.depth + 1;
+            const bool empty = nd.child[c] < 0 && ((~nd.child[c]) & 3) == 3;
+            for (int k = 0; k < 3; k++) {
+                next.lo[k] = (double)H.bvh.grid_base[k] + (double)nd.q[c * 6 + k] * H.bvh.grid_scale[k];
+                next.hi[k] = (double)H.bvh.grid_base[k] + (double)nd.q[c * 6 + 3 + k] * H.bvh.grid_scale[k];
+                // a child's box may be wider than its parent's (each is rounded outward on
+                // its own) but must hold what lies beneath, which the leaves check
+            }
+            if (!empty) todo.push_back(next);
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptk_check_scene(const ptk_scene_desc* k, ptk_scene_stats* stats)
+{
+    if (!k) return fail(PTK_ERR_ARG, "ptk_check_scene: null argument");
+    HostBigScene H;
+    int rc = compile_big_scene(k, 0, H);
     if (rc != PTK_OK) return rc;
+    const int n = H.d.num_shapes;
+    std::vector<uint8_t> seen((size_t)n + 1, 0);
+    int max_depth = 0;
+    const uint16_t whole[6] = {0, 0, 0, 65535, 65535, 65535};
+    if (!check_subtree(H, 0, whole, seen, 0, max_depth))
+        return fail(PTK_ERR_STATE, "ptk_check_scene: the hierarchy is inconsistent");
+    for (int s = 0; s < n; s++)
+        if (!seen[(size_t)s]) return fail(PTK_ERR_STATE, "ptk_check_scene: shape %d is in no leaf", s);
+    if (max_depth > PTK_BVH_STACK - 2 || max_depth != H.bvh.depth)
+        return fail(PTK_ERR_STATE, "ptk_check_scene: depth %d (builder says %d)", max_depth, H.bvh.depth);
+    fill_scene_stats(H, 0, stats);
+    return PTK_OK;
+}
+
+int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features,
+                  ptk_scene_stats* stats)
+{
+    if (!c || !k) return fail(PTK_ERR_ARG, "ptk_set_scene: null argument");
+    HostBigScene H;
+    int rc = compile_big_scene(k, want_denoise_features, H);
+    if (rc != PTK_OK) return rc;
+    const int feats = H.d.want_features;
+    const bool has_blur = H.has_blur, any_dielectric = H.any_dielectric;
+    const DevScene& d = H.d;
+    BvhBuild& bvh = H.bvh;
+    std::vector<LeafRec>& recs = H.recs;
+    std::vector<float>& rot = H.rot;
+    std::vector<float>& face_normal = H.face_normal;
+    std::vector<DevShape>& shapes = H.shapes;
+    std::vector<int32_t>& imp = H.imp;
+
+    if ((rc = bind(c)) != PTK_OK) return rc;
     if ((rc = ensure_image(c, k->res_h, k->res_v)) != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_big_scene(c);
@@ -602,14 +735,7 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = true;
-    if (stats) {
-        stats->num_shapes = n;
-        stats->nodes = (int32_t)bvh.nodes.size();
-        stats->leaves = bvh.leaves;
-        stats->depth = bvh.depth;
-        stats->build_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-        stats->device_bytes = total;
-    }
+    fill_scene_stats(H, total, stats);
     return ptk_reset_accumulators(c);
 }
 

@@ -26,6 +26,7 @@ EXPORTS = [
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
     "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_save_target",
     "ptk_set_target", "ptk_train_step", "ptk_timing", "ptk_synchronize", "ptk_set_scene",
+    "ptk_check_scene",
 ]
 SCENE_VISIT_ALL = 1
 SCENE_ATTRS = 13
@@ -157,6 +158,7 @@ def load():
     L.ptk_set_target.argtypes = [vp, fp]
     L.ptk_train_step.argtypes = [vp, fp, fp, fp, C.c_int, C.c_float, fp]
     L.ptk_set_scene.argtypes = [vp, C.POINTER(SceneDesc), C.c_int, C.POINTER(SceneStats)]
+    L.ptk_check_scene.argtypes = [C.POINTER(SceneDesc), C.POINTER(SceneStats)]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
     for name in EXPORTS:
@@ -171,6 +173,19 @@ def _fp(a):
         return None
     assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def check_scene(scene, flags=0):
+    """ptk_check_scene: validates a scene dict and verifies the hierarchy built for it, on the
+    host alone.  Returns the statistics as a dict; raises PtkError on a bad scene."""
+    L = load()
+    d, keep = scene_desc(scene, flags)
+    st = SceneStats()
+    rc = L.ptk_check_scene(C.byref(d), C.byref(st))
+    del keep
+    if rc != 0:
+        raise PtkError("libptk error %d: %s" % (rc, L.ptk_last_error().decode()))
+    return {k: getattr(st, k) for k, _ in SceneStats._fields_}
 
 
 class Context:
