@@ -1,6 +1,7 @@
 // ptk_host.cpp -- the reference-shaped host façade over libptk (see ptk_host.h).
 #include "ptk_host.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -248,6 +249,86 @@ void fill_constants(const HostState& st, const Scene& scene, ptk_constants& k)
     }
     k.num_shapes = added;
 }
+
+// Whether the scene fits the reference's POD (50 shapes, 450 attribute floats, 50
+// materials, 10 important shapes; headers/GLOBALS.h:80-94).
+bool fits_pod(const Scene& scene)
+{
+    size_t attrs = 0;
+    for (const Obj& o : scene.objList) attrs += o.type == 0 ? 4 : 13;
+    return scene.objList.size() <= PTK_MAX_SHAPES && attrs <= PTK_MAX_ATTRS &&
+           scene.matList.size() <= PTK_MAX_MATS && scene.importantList.size() <= PTK_MAX_IMPORTANT;
+}
+
+// The same tables without the limits, for ptk_set_scene.
+struct SceneTables {
+    ptk_scene_desc desc;
+    std::vector<int32_t> type, mat;
+    std::vector<float> attrs, mats;
+    std::vector<uint32_t> imp;
+};
+void fill_tables(const HostState& st, const Scene& scene, const ptk_constants& k, SceneTables& t)
+{
+    std::memset(&t.desc, 0, sizeof t.desc);
+    for (int i = 0; i < 3; i++) {
+        t.desc.cam_pos[i] = k.cam_pos[i];
+        t.desc.cam_forward[i] = k.cam_forward[i];
+        t.desc.cam_right[i] = k.cam_right[i];
+        t.desc.cam_up[i] = k.cam_up[i];
+    }
+    t.desc.rand_samp = k.rand_samp;
+    t.desc.max_depth = k.max_depth;
+    t.desc.res_v = k.res_v;
+    t.desc.res_h = k.res_h;
+    t.desc.max_angle_v = k.max_angle_v;
+    t.desc.max_angle_h = k.max_angle_h;
+    t.desc.focal_length = k.focal_length;
+    const size_t n = scene.objList.size();
+    t.type.assign(n, 0);
+    t.mat.assign(n, 0);
+    t.attrs.assign(n * PTK_SCENE_ATTRS, 0.0f);
+    for (size_t s = 0; s < n; s++) {
+        const Obj& o = scene.objList[s];
+        t.type[s] = o.type;
+        t.mat[s] = o.mat_ind;
+        float* a = &t.attrs[s * PTK_SCENE_ATTRS];
+        a[0] = o.pos.x; a[1] = o.pos.y; a[2] = o.pos.z;
+        if (o.type == 0) {
+            a[3] = o.r;
+        } else {
+            a[3] = o.pos.x + o.min.x; a[4] = o.pos.y + o.min.y; a[5] = o.pos.z + o.min.z;
+            a[6] = o.pos.x + o.max.x; a[7] = o.pos.y + o.max.y; a[8] = o.pos.z + o.max.z;
+            for (int i = 0; i < 4; i++) a[9 + i] = o.q[i];
+        }
+    }
+    t.mats.assign(std::max<size_t>(1, scene.matList.size()) * 6, 0.0f);
+    for (size_t m = 0; m < scene.matList.size(); m++) {
+        const Mat& mm = scene.matList[m];
+        const float row[6] = {mm.alb.x, mm.alb.y, mm.alb.z, mm.blur, mm.RI, (float)mm.matType};
+        std::memcpy(&t.mats[m * 6], row, sizeof row);
+    }
+    t.imp.clear();
+    for (int i : scene.importantList) t.imp.push_back((uint32_t)i);
+    t.desc.num_shapes = (int32_t)n;
+    t.desc.num_mats = (int32_t)(t.mats.size() / 6);
+    t.desc.num_important_shapes = (int32_t)t.imp.size();
+    t.desc.shape_type = t.type.data();
+    t.desc.shape_mat = t.mat.data();
+    t.desc.shape_attrs = t.attrs.data();
+    t.desc.mat_list = t.mats.data();
+    t.desc.important_shapes = t.imp.data();
+    (void)st;
+}
+
+// Hands the scene to the device: the POD when it fits (the reference's path,
+// CUDARender::UpdateConstants), the tables behind a hierarchy otherwise.
+int push_scene(HostState& st, const ptk_constants& k)
+{
+    if (fits_pod(st.scene)) return ptk_set_constants(st.ctx, &k, sizeof k, -1);
+    SceneTables t;
+    fill_tables(st, st.scene, k, t);
+    return ptk_set_scene(st.ctx, &t.desc, k.get_denoiser_inf == 1 ? 1 : 0, nullptr);
+}
 }  // namespace
 
 void Renderers::UpdateCam(bool push)
@@ -260,8 +341,7 @@ void Renderers::UpdateCam(bool push)
     constants.res_h = st_->xRes;
     constants.res_v = st_->yRes;
     if (push && st_->ctx) {
-        st_->check(ptk_set_constants(st_->ctx, &constants, sizeof constants, -1),
-                   "ptk_set_constants");
+        st_->check(push_scene(*st_, constants), "ptk_set_constants / ptk_set_scene");
         st_->sampleCount = 0;
     }
 }
@@ -277,7 +357,7 @@ void Renderers::UpdateConstants()
     GloRandS[1] = ms;
     if (!st_->ctx) st_->check(ptk_create(st_->device, &st_->ctx), "ptk_create");
     if (!st_->ctx) return;
-    st_->check(ptk_set_constants(st_->ctx, &constants, sizeof constants, -1), "ptk_set_constants");
+    st_->check(push_scene(*st_, constants), "ptk_set_constants / ptk_set_scene");
     st_->check(ptk_set_math_mode(st_->ctx, st_->mathMode), "ptk_set_math_mode");
     st_->sampleCount = 0;
     st_->InitScreens();
@@ -547,6 +627,42 @@ extern "C" int ptkhost_scene_constants(const char* scene_path, int width, int he
     ptk_constants k;
     ptkhost::fill_constants(st, st.scene, k);
     std::memcpy(constants_out, &k, sizeof k);
+    if (exposure_out) *exposure_out = st.exposure;
+    if (gamma_out) *gamma_out = st.g;
+    return 0;
+}
+
+// The tables the facade hands to ptk_set_scene for a scene file of any size.
+// Arrays may be null to query the counts (returned in desc_out's num_* fields).
+extern "C" int ptkhost_scene_tables(const char* scene_path, int width, int height, int max_depth,
+                                    float rand_samp, int denoising, ptk_scene_desc* desc_out,
+                                    int32_t* shape_type, int32_t* shape_mat, float* shape_attrs,
+                                    float* mat_list, uint32_t* important, float* exposure_out,
+                                    float* gamma_out)
+{
+    if (!scene_path || !desc_out) return -1;
+    ptkhost::HostState st;
+    st.xRes = width;
+    st.yRes = height;
+    st.maxDepth = max_depth;
+    st.randSamp = rand_samp;
+    st.denoising = denoising != 0;
+    if (!st.scene.LoadScene(scene_path)) return -1;
+    ptk_constants k;
+    ptkhost::fill_constants(st, st.scene, k);
+    ptkhost::SceneTables t;
+    ptkhost::fill_tables(st, st.scene, k, t);
+    *desc_out = t.desc;
+    desc_out->shape_type = nullptr;
+    desc_out->shape_mat = nullptr;
+    desc_out->shape_attrs = nullptr;
+    desc_out->mat_list = nullptr;
+    desc_out->important_shapes = nullptr;
+    if (shape_type) std::memcpy(shape_type, t.type.data(), t.type.size() * sizeof(int32_t));
+    if (shape_mat) std::memcpy(shape_mat, t.mat.data(), t.mat.size() * sizeof(int32_t));
+    if (shape_attrs) std::memcpy(shape_attrs, t.attrs.data(), t.attrs.size() * sizeof(float));
+    if (mat_list) std::memcpy(mat_list, t.mats.data(), t.mats.size() * sizeof(float));
+    if (important) std::memcpy(important, t.imp.data(), t.imp.size() * sizeof(uint32_t));
     if (exposure_out) *exposure_out = st.exposure;
     if (gamma_out) *gamma_out = st.g;
     return 0;

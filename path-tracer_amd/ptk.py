@@ -407,6 +407,39 @@ def scene_constants(path, width, height, max_depth=4, rand_samp=0.005, denoising
     return buf.raw, float(e.value), float(g.value)
 
 
+def scene_tables(path, width, height, max_depth=4, rand_samp=0.005, denoising=False):
+    """Scene file of any size -> (scene dict for Context.set_scene, exposure, gamma): the
+    tables the host facade hands to ptk_set_scene when a scene exceeds the reference's POD."""
+    H = _load_host()
+    H.ptkhost_scene_tables.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                       C.POINTER(SceneDesc), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float), C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    H.ptkhost_scene_tables.restype = C.c_int
+    d = SceneDesc()
+    args = (os.fsencode(path), width, height, max_depth, C.c_float(rand_samp), int(bool(denoising)))
+    if H.ptkhost_scene_tables(*args, C.byref(d), None, None, None, None, None, None, None) != 0:
+        raise PtkError("cannot load scene %s" % path)
+    st = np.zeros(d.num_shapes, np.int32)
+    sm = np.zeros(d.num_shapes, np.int32)
+    sa = np.zeros((d.num_shapes, SCENE_ATTRS), np.float32)
+    ml = np.zeros((d.num_mats, 6), np.float32)
+    im = np.zeros(d.num_important_shapes, np.uint32)
+    e, g = C.c_float(0), C.c_float(0)
+    i32, u32 = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    rc = H.ptkhost_scene_tables(*args, C.byref(d), st.ctypes.data_as(i32), sm.ctypes.data_as(i32),
+                                _fp(sa), _fp(ml), im.ctypes.data_as(u32), C.byref(e), C.byref(g))
+    if rc != 0:
+        raise PtkError("cannot load scene %s" % path)
+    scene = dict(cam_pos=list(d.cam_pos), cam_forward=list(d.cam_forward),
+                 cam_right=list(d.cam_right), cam_up=list(d.cam_up), rand_samp=d.rand_samp,
+                 max_depth=d.max_depth, res_v=d.res_v, res_h=d.res_h, max_angle_v=d.max_angle_v,
+                 max_angle_h=d.max_angle_h, focal_length=d.focal_length, shape_type=st,
+                 shape_mat=sm, shape_attrs=sa, mat_list=ml, important_shapes=im)
+    return scene, float(e.value), float(g.value)
+
+
 def load_weights(path):
     """Weights file -> (w12[360], w23[100], w34[70]) via DenoiserNN::LoadWeights."""
     w12, w23, w34 = np.zeros(360, np.float32), np.zeros(100, np.float32), np.zeros(70, np.float32)

@@ -53,6 +53,55 @@ def test_headless_ppm_equals_the_abi_pipeline(tmp_path, denoise):
     assert np.array_equal(np.clip(got, 0, 255), rgb.astype(np.int64))
 
 
+def _write_big_scene(path, n, seed=3):
+    """A scene file with more shapes than the reference's POD holds (n > 50), in the
+    reference's format (headers/Scene.h:226-274)."""
+    rng = np.random.default_rng(seed)
+    lines = ["m 0.73/0.73/0.73 0 1 0", "m 0.65/0.05/0.05 0 1 0", "m 0.12/0.45/0.15 0 1 0",
+             "m 6/6/6 0 1 1", "m 1/1/1 0 1 2", "m 1/1/1 0 1.5 3"]
+    lines += ["o 1", "d 0/-6/8 -30/0/-12 30/0/30 0/0/0 0"]          # floor
+    lines += ["o 0", "d 0/9/8 2 3"]                                   # light
+    for k in range(n - 2):
+        c = rng.uniform([-10, -5, 2], [10, 6, 20])
+        mat = int(rng.choice([0, 1, 2, 4, 5]))
+        if rng.random() < 0.5:
+            lines += ["o 0", "d %.4f/%.4f/%.4f %.4f %d" % (c[0], c[1], c[2], rng.uniform(0.2, 0.6), mat)]
+        else:
+            h = rng.uniform(0.2, 0.7, 3)
+            rot = rng.uniform(0, 3.0, 3) if rng.random() < 0.4 else np.zeros(3)
+            lines += ["o 1", "d %.4f/%.4f/%.4f %.4f/%.4f/%.4f %.4f/%.4f/%.4f %.3f/%.3f/%.3f %d" % (
+                c[0], c[1], c[2], -h[0], -h[1], -h[2], h[0], h[1], h[2], rot[0], rot[1], rot[2], mat)]
+    lines += ["i 1", "c 0/0/-9 0/0/1 0/1/0 1/0/0 90 120", "pp 1.5 2.2"]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def test_headless_scene_beyond_the_pod_goes_through_the_hierarchy(tmp_path):
+    """A scene file of 400 shapes: the facade routes it to ptk_set_scene; the frame equals the
+    one the ABI gives for the tables the facade built."""
+    import ptk
+    W, H, spp = 96, 54, 6
+    scene_file = str(tmp_path / "big.scene")
+    _write_big_scene(scene_file, 400)
+    ppm = str(tmp_path / "big.ppm")
+    r = subprocess.run([HEADLESS, "--scene", scene_file, "--res", "%dx%d" % (W, H), "--spp", str(spp),
+                        "--counter-seeds", "--ppm", ppm, "--dump", str(tmp_path / "d")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    scene, exposure, gamma = ptk.scene_tables(scene_file, W, H)
+    assert len(scene["shape_type"]) == 400 and abs(exposure - 1.5) < 1e-6
+    ctx = ptk.Context(0)
+    ctx.set_scene(scene)
+    ctx.render(spp, ptk.SEED_COUNTER)
+    _, rgb = ctx.post_process(0, exposure, gamma, want_post=False, want_rgb8=True)
+    pre = ctx.read_accumulators()["preScreen"]
+    ctx.close()
+    assert np.array_equal(np.fromfile(str(tmp_path / "d.preScreen.f32"), np.float32),
+                          pre.reshape(-1))
+    assert np.array_equal(np.clip(_read_ppm(ppm), 0, 255), rgb.astype(np.int64))
+    assert pre.mean() > 0.01
+
+
 def test_headless_rejects_bad_arguments(tmp_path):
     r = subprocess.run([HEADLESS], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
