@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: kernel-trace statistics of the default bench command and the
-# PMC passes (one counter block per pass) that DESIGN.md and bench.py's roofline cite.
+# PMC passes (one counter block per pass) behind bench.py's roofline object.
 # Usage: scripts/collect_profiles.sh <tag>      (outputs under gpurun_out/<tag>/)
 set -e
 cd "$(dirname "$0")/.."

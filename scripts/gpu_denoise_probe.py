@@ -1,4 +1,5 @@
-"""Denoiser micro-benchmark on synthetic accumulators (no render): SURVEY 8d inputs."""
+"""Denoiser micro-benchmark on synthetic accumulators (no render): seed 1234, colour and albedo in U[0,1],
+normalised normal, worldPos in U[-10,10], directLight in {0, 1/4, .., 1}, stdDev in U[1e-4, 0.5], 128 spp."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))

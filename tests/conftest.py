@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "path-tracer_amd")):
 DATA = os.path.join(ROOT, "data")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# Seed used for every recorded reference run (BASELINE.md section 2).
+# Seed used for every recorded reference run.
 PIN_SEED = (0x9E3779B97F4A7C15, 0xD1B54A32D192ED03)
 
 

@@ -2,9 +2,9 @@
 
 The reference cannot be compiled in this image (its sources include <skepu>
 and ext/imgui.h, which are absent) and ships no tests.  The numbers below are
-outputs of the reference's own sequential backend, recorded in BASELINE.md
-section 2 and SURVEY.md appendix C from a g++/<cmath> build of
-Renderers.cpp / Denoiser.cpp / DenoiserNN.cpp with GloRandS pinned:
+outputs of the reference's own sequential backend, recorded when this work was
+scoped from a g++/<cmath> build of Renderers.cpp / Denoiser.cpp /
+DenoiserNN.cpp with GloRandS pinned:
 
   * cornell 512x512, 4 spp, maxDepth 4, randSamp 0.005:
       image means 0.219705 / 0.179140 / 0.129321, CPUAutoExp ~7.4e6
@@ -77,7 +77,7 @@ def test_denoiser_means_match_recorded_reference_run(oracle):
     acc, n, _ = _render_with(O.lib(), O, consts, W, H, 4)
     w = O.load_weights(weights_path("BEST"))
     feats, var = O.forward_prop(acc, W, H, n, w, threads=8)
-    # BEST.txt saturates the bandwidth outputs ("~19-23")
+    # BEST.txt saturates the bandwidth outputs (recorded from the reference: about 19 to 23)
     assert 18.5 < var.min() and var.max() < 23.5
     den, wc = O.filter(acc, var, W, H, n, 1, threads=8)
     assert "%.4f" % den[:, 0].astype(np.float64).mean() == "0.0640"
