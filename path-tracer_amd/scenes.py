@@ -26,15 +26,18 @@ def _unit_quaternions(rng, n):
 
 
 def random_scene(n, width, height, seed=1, dielectric=True, blur=False, max_depth=4,
-                 extent=12.0, lights=4):
+                 extent=12.0, lights=4, extra_mats=0):
     """n shapes scattered in a room: spheres, boxes (a third of them rotated, a few flat),
-    lambert / metal / dielectric materials, `lights` emissive shapes listed as important."""
+    lambert / metal / dielectric materials (plus extra_mats random lambert ones), `lights`
+    emissive shapes listed as important."""
     rng = np.random.default_rng(seed)
     mats = [[0.8, 0.8, 0.8, 0, 0, 0], [0.9, 0.3, 0.3, 0, 0, 0], [0.3, 0.9, 0.3, 0, 0, 0],
             [0.3, 0.3, 0.9, 0, 0, 0], [12.0, 12.0, 12.0, 0, 0, 1],
             [0.9, 0.9, 0.9, 0.1 if blur else 0.0, 0, 2]]
     if dielectric:
         mats.append([1.0, 1.0, 1.0, 0.05 if blur else 0.0, 1.5, 3])
+    for _ in range(extra_mats):
+        mats.append([*rng.uniform(0.2, 0.95, 3), 0, 0, 0])
     mats = np.asarray(mats, np.float32)
     kinds = np.arange(len(mats))
     kinds = kinds[kinds != 4]

@@ -102,6 +102,28 @@ def test_against_index_order_scan_on_cpu(ctx, oracle, n, dielectric):
     assert abs(gpu[0:3].mean() - acc[0:3].mean()) <= 2e-3 * acc[0:3].mean()
 
 
+def test_tables_beyond_every_pod_limit(ctx, oracle):
+    """More than 50 shapes, more than 127 materials (the fixed-size kernel's record
+    holds 7 bits), more than 10 important shapes, at once."""
+    import ptk
+    import scenes
+    W, H = 64, 36
+    sc = scenes.random_scene(900, W, H, seed=21, lights=40, extra_mats=400)
+    assert len(sc["mat_list"]) > 400 and len(sc["important_shapes"]) == 40
+    assert sc["shape_mat"].max() > 127
+    ctx.set_scene(sc, want_features=1)
+    rays, glo = ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    gpu = ctx.read_planes()
+    ctx.set_scene(sc, want_features=1, flags=ptk.SCENE_VISIT_ALL)
+    ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    assert _same(gpu, ctx.read_planes()).all()
+    acc = oracle.new_accumulators(W, H)
+    _, glo_o, rays_o = oracle.render_scene(sc, acc, 2, 0, PIN_SEED, want_features=True, threads=8)
+    assert glo == glo_o
+    assert _same(gpu[0:3], acc[0:3]).all(axis=0).mean() >= 0.98
+    assert _same(gpu[6:9], acc[6:9]).all(axis=0).mean() >= 0.995    # first-hit albedo: the material
+
+
 @pytest.mark.parametrize("n", [0, 1, 3, 5])
 def test_tiny_scenes(ctx, oracle, n):
     import ptk
