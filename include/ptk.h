@@ -182,6 +182,15 @@ int ptk_set_scene(ptk_ctx* ctx, const ptk_scene_desc* scene, int want_denoise_fe
  * optional (device_bytes is 0). */
 int ptk_check_scene(const ptk_scene_desc* scene, ptk_scene_stats* stats);
 
+/* Replaces the camera half of Renderers::UpdateCam (Renderers.cpp:1132-1149) for
+ * the scene already set by ptk_set_constants or ptk_set_scene: new camera
+ * position and axes, everything else (shapes, materials, resolution, and for
+ * ptk_set_scene the hierarchy) kept; the accumulators are reset.  A
+ * ptk_set_scene scene pads its bounds for the extent of the scene including the
+ * camera; a position beyond that extent is PTK_ERR_ARG (set the scene again). */
+int ptk_set_camera(ptk_ctx* ctx, const float cam_pos[3], const float cam_forward[3],
+                   const float cam_right[3], const float cam_up[3]);
+
 /* The zeroing half of PT::RefreshScreen (PT.cpp:159-169): sampleCount = 0 and
  * all planes cleared. */
 int ptk_reset_accumulators(ptk_ctx* ctx);

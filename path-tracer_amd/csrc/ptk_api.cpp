@@ -63,6 +63,7 @@ struct ptk_ctx {
     BigScene big = {};
     void* big_alloc[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool has_blur = false;
+    double big_extent = 0.0;          // what a ptk_set_scene scene's bounds were padded for
 
     float* planes_d = nullptr;        // PTK_N_PLANES * pixels
     int64_t* seeds_d = nullptr;       // seed chunk
@@ -421,6 +422,7 @@ struct HostBigScene {
     BvhBuild bvh;
     bool has_blur = false, any_dielectric = false;
     double build_ms = 0.0;
+    double extent = 0.0;
 };
 
 int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBigScene& H)
@@ -515,6 +517,7 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
 
     if (extent > 1e6)
         return fail(PTK_ERR_ARG, "ptk_set_scene: coordinates up to %g exceed 1e6", extent);
+    H.extent = extent;
 
     // ---- bounds.  A shape test accepts a ray only if the ray passes the shape
     // within the test's rounding error, which grows with the distances involved
@@ -727,6 +730,7 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     c->big.any_dielectric = any_dielectric ? 1 : 0;
     c->big.visit_all = (k->flags & PTK_SCENE_VISIT_ALL) ? 1 : 0;
     c->big_scene = true;
+    c->big_extent = H.extent;
     c->has_blur = has_blur;
     c->host_scene = d;
     c->max_depth = k->max_depth;
@@ -736,6 +740,36 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = true;
     fill_scene_stats(H, total, stats);
+    return ptk_reset_accumulators(c);
+}
+
+int ptk_set_camera(ptk_ctx* c, const float* pos, const float* fwd, const float* right,
+                   const float* up)
+{
+    if (!c || !pos || !fwd || !right || !up) return fail(PTK_ERR_ARG, "ptk_set_camera: null argument");
+    if (!c->have_scene) return fail(PTK_ERR_STATE, "ptk_set_camera before a scene was set");
+    for (int i = 0; i < 3; i++) {
+        if (!std::isfinite(pos[i]) || !std::isfinite(fwd[i]) || !std::isfinite(right[i]) ||
+            !std::isfinite(up[i]))
+            return fail(PTK_ERR_ARG, "ptk_set_camera: component %d is not finite", i);
+        if (c->big_scene && std::fabs((double)pos[i]) > c->big_extent)
+            return fail(PTK_ERR_ARG,
+                        "ptk_set_camera: position %g lies beyond the extent %g the scene's bounds "
+                        "were padded for; call ptk_set_scene again", (double)pos[i], c->big_extent);
+    }
+    int rc = bind(c);
+    if (rc != PTK_OK) return rc;
+    for (int i = 0; i < 3; i++) {
+        c->host_scene.cam_pos[i] = pos[i];
+        c->host_scene.cam_fwd[i] = fwd[i];
+        c->host_scene.cam_right[i] = right[i];
+        c->host_scene.cam_up[i] = up[i];
+    }
+    // the four vectors lead the structure
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scene_d, &c->host_scene, offsetof(DevScene, rand_samp),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return ptk_reset_accumulators(c);
 }
 

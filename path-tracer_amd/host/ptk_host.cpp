@@ -341,7 +341,18 @@ void Renderers::UpdateCam(bool push)
     constants.res_h = st_->xRes;
     constants.res_v = st_->yRes;
     if (push && st_->ctx) {
-        st_->check(push_scene(*st_, constants), "ptk_set_constants / ptk_set_scene");
+        // only the camera moved since the scene was handed over: keep the compiled scene
+        // (and, for a scene beyond the POD, its hierarchy)
+        int rc = -1;
+        if (scenePushed_ && pushedW_ == st_->xRes && pushedH_ == st_->yRes)
+            rc = ptk_set_camera(st_->ctx, constants.cam_pos, constants.cam_forward,
+                                constants.cam_right, constants.cam_up);
+        if (rc != PTK_OK) {
+            st_->check(push_scene(*st_, constants), "ptk_set_constants / ptk_set_scene");
+            scenePushed_ = st_->ok();
+            pushedW_ = st_->xRes;
+            pushedH_ = st_->yRes;
+        }
         st_->sampleCount = 0;
     }
 }
@@ -358,6 +369,9 @@ void Renderers::UpdateConstants()
     if (!st_->ctx) st_->check(ptk_create(st_->device, &st_->ctx), "ptk_create");
     if (!st_->ctx) return;
     st_->check(push_scene(*st_, constants), "ptk_set_constants / ptk_set_scene");
+    scenePushed_ = st_->ok();
+    pushedW_ = st_->xRes;
+    pushedH_ = st_->yRes;
     st_->check(ptk_set_math_mode(st_->ctx, st_->mathMode), "ptk_set_math_mode");
     st_->sampleCount = 0;
     st_->InitScreens();

@@ -80,6 +80,8 @@ public:
 
 private:
     HostState* st_;
+    bool scenePushed_ = false;       // the device holds this scene at pushedW_ x pushedH_
+    int pushedW_ = 0, pushedH_ = 0;
 };
 
 // headers/DenoiserNN.h:95-219 (inference part).

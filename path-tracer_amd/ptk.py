@@ -26,7 +26,7 @@ EXPORTS = [
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
     "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_save_target",
     "ptk_set_target", "ptk_train_step", "ptk_timing", "ptk_synchronize", "ptk_set_scene",
-    "ptk_check_scene",
+    "ptk_check_scene", "ptk_set_camera",
 ]
 SCENE_VISIT_ALL = 1
 SCENE_ATTRS = 13
@@ -158,6 +158,7 @@ def load():
     L.ptk_set_target.argtypes = [vp, fp]
     L.ptk_train_step.argtypes = [vp, fp, fp, fp, C.c_int, C.c_float, fp]
     L.ptk_set_scene.argtypes = [vp, C.POINTER(SceneDesc), C.c_int, C.POINTER(SceneStats)]
+    L.ptk_set_camera.argtypes = [vp, fp, fp, fp, fp]
     L.ptk_check_scene.argtypes = [C.POINTER(SceneDesc), C.POINTER(SceneStats)]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
@@ -229,6 +230,10 @@ class Context:
         del keep
         self.height, self.width = int(d.res_v), int(d.res_h)
         return {k: getattr(st, k) for k, _ in SceneStats._fields_}
+
+    def set_camera(self, pos, forward, right, up):
+        v = [np.ascontiguousarray(x, dtype=np.float32) for x in (pos, forward, right, up)]
+        self._check(self._L.ptk_set_camera(self._h, *[_fp(x) for x in v]))
 
     @property
     def pixels(self):

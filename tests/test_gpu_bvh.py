@@ -163,6 +163,40 @@ def test_counter_seeds_and_statistics(ctx):
     assert np.isfinite(ctx.read_planes(0, 3)).all()
 
 
+def test_camera_moves_keep_the_scene(ctx):
+    """ptk_set_camera: the same frame as setting the whole scene again with that camera, for
+    both kinds of scene; a position beyond the padded extent is refused."""
+    import os
+    import ptk
+    import scenes
+    sc = scenes.random_scene(700, 64, 36, seed=31)
+    pos = np.float32([1.5, 2.0, -0.5])
+    c, s_ = np.float32(np.cos(0.3)), np.float32(np.sin(0.3))
+    fwd, right, up = np.float32([s_, 0, c]), np.float32([c, 0, -s_]), np.float32([0, 1, 0])
+    ctx.set_scene(sc, want_features=1)
+    ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)          # something to be reset
+    ctx.set_camera(pos, fwd, right, up)
+    assert ctx.sample_count == 0
+    ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    a = ctx.read_planes()
+    moved = dict(sc, cam_pos=pos, cam_forward=fwd, cam_right=right, cam_up=up)
+    ctx.set_scene(moved, want_features=1)
+    ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    assert _same(a, ctx.read_planes()).all()
+    with pytest.raises(ptk.PtkError, match="extent"):
+        ctx.set_camera(np.float32([1e4, 0, 0]), fwd, right, up)
+
+    raw = bytearray(np.load(os.path.join(GOLDEN, "render_cornell_crystal_64x36.npz"))["constants"].tobytes())
+    ctx.set_constants(bytes(raw), want_features=1)
+    ctx.set_camera(np.float32([0.5, -2.0, -8.0]), fwd, right, up)
+    ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    a = ctx.read_planes()
+    np.frombuffer(raw, np.float32)[0:12] = np.concatenate([np.float32([0.5, -2.0, -8.0]), fwd, right, up])
+    ctx.set_constants(bytes(raw), want_features=1)
+    ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+    assert _same(a, ctx.read_planes()).all()
+
+
 def test_bad_scenes_are_rejected(ctx):
     import ptk
     import scenes
