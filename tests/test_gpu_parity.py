@@ -237,6 +237,43 @@ def test_counter_seeds_are_deterministic_and_additive(ctx, oracle):
     assert raw > 0 and np.isfinite(e)
 
 
+@pytest.mark.parametrize("name", ["cornell_crystal", "MultiLightGlass"])
+def test_full_size_frame_spot_checked_against_the_cpu(ctx, oracle, name):
+    """1920x1080 with the reference's sequential seed stream (33 MB of seeds per pass): two
+    passes on the GPU, then 4000 pixels drawn at random are recomputed on the CPU from the
+    same seeds.  Same bar as the small frames: >= 99 % of them bit-identical per sample."""
+    import ptk
+    O = oracle
+    W, H = 1920, 1080
+    P = W * H
+    consts = O.build_constants(O.load_scene(scene_path(name)), W, H, 4, 0.005, True)
+    ctx.set_constants(consts)
+    rays, glo = ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    first = ctx.read_planes(0, 16)
+    seeds1, glo1 = O.seed_stream(PIN_SEED, P)
+    assert glo == glo1
+    rays2, glo2 = ctx.render(1, ptk.SEED_REFERENCE, glo)
+    both = ctx.read_planes(0, 16)
+    seeds2, glo_end = O.seed_stream(glo1, P)
+    assert glo2 == glo_end
+    rng = np.random.default_rng(5)
+    picks = rng.choice(P, 4000, replace=False)
+    same1 = same2 = 0
+    for i in picks:
+        row, col = divmod(int(i), W)
+        s = O.render_sample(consts, row, col, int(seeds1[i, 0]), int(seeds1[i, 1]))
+        ref1 = np.float32(list(s.xyz) + list(s.normal) + list(s.albedo1) + list(s.albedo2)
+                          + list(s.world_pos) + [s.direct_light])
+        ok1 = np.array_equal(first[:, i], ref1, equal_nan=True)
+        same1 += ok1
+        s = O.render_sample(consts, row, col, int(seeds2[i, 0]), int(seeds2[i, 1]))
+        ref2 = np.float32(list(s.xyz) + list(s.normal) + list(s.albedo1) + list(s.albedo2)
+                          + list(s.world_pos) + [s.direct_light])
+        same2 += ok1 and np.array_equal(both[:, i], ref1 + ref2, equal_nan=True)
+    assert same1 >= 0.99 * len(picks)
+    assert same2 >= 0.98 * len(picks)
+
+
 def test_counter_seeded_image_converges_to_the_reference_seeded_one(ctx, oracle):
     """RMSE bound: 64 spp with device seeds against 64 spp with the reference's seed
     stream, both on the GPU, and the latter against the oracle's mean."""
@@ -290,6 +327,50 @@ def test_denoise_row_bands_tile_the_full_result(ctx, oracle):
         ctx.denoise_rows(w, 1, 0, 10, 5)
     with pytest.raises(ptk.PtkError):
         ctx.denoise_rows(w, 1, 0, 0, H + 1)
+
+
+def test_full_size_denoise_properties(ctx, oracle):
+    """1920x1080, 16 spp with features, BEST.txt: the eight row bands of an 8-GPU split tile
+    the whole-frame result bit for bit; the fused and the two-pass forms agree to rounding;
+    the bandwidths of twelve random 48x48 crops recomputed on the CPU from the read-back
+    accumulators agree within the small-frame tolerance."""
+    import ptk
+    import torch
+    import multigpu
+    O = oracle
+    W, H = 1920, 1080
+    sc = O.load_scene(scene_path("MultiLightGlass"))
+    ctx.set_constants(O.build_constants(sc, W, H, 4, 0.005, True))
+    w = O.load_weights(weights_path("BEST"))
+    ctx.render(16, ptk.SEED_COUNTER)
+    full = ctx.denoise(w, 1, 0)
+    fused = ctx.denoise(w, 1, 1)
+    ok = np.isfinite(full["denoised"]) & np.isfinite(fused["denoised"])
+    assert ok.mean() > 0.999
+    assert np.allclose(fused["denoised"][ok], full["denoised"][ok], rtol=2e-5, atol=1e-7)
+    den, wc = multigpu.device_denoised(ctx, torch.device("cuda", 0))
+    den.zero_()
+    wc.zero_()
+    torch.cuda.synchronize()
+    for r in range(8):
+        y0, y1 = multigpu.row_band(H, 8, r)
+        ctx.denoise_rows(w, 1, 0, y0, y1)
+    assert np.array_equal(den.cpu().numpy().T, full["denoised"], equal_nan=True)
+    # bandwidths of random pixels against the CPU, computed from a crop around each
+    planes = ctx.read_planes()
+    rng = np.random.default_rng(9)
+    var_gpu = full["variances"]
+    checked = 0
+    for _ in range(12):
+        x0, y0 = int(rng.integers(0, W - 48)), int(rng.integers(0, H - 48))
+        crop = np.ascontiguousarray(planes.reshape(-1, H, W)[:, y0:y0 + 48, x0:x0 + 48]).reshape(-1, 48 * 48)
+        _, var = O.forward_prop(crop, 48, 48, 16, w, threads=4)
+        inner = np.zeros((48, 48), bool)
+        inner[3:45, 3:45] = True              # the crop's own edges clamp differently
+        g = var_gpu.reshape(H, W, 7)[y0:y0 + 48, x0:x0 + 48][inner]
+        assert np.allclose(g, var.reshape(48, 48, 7)[inner], rtol=2e-5, atol=1e-7)
+        checked += int(inner.sum())
+    assert checked > 20000
 
 
 def test_post_process_matches_the_display_transform(ctx, oracle):
