@@ -1,16 +1,30 @@
 // bvh_build.cpp -- binned surface-area-heuristic build, top down, with a switch
 // to median splits once a branch is deep enough that an unbalanced tree could
 // outgrow the kernels' traversal stack.
+//
+// One shape per leaf, so a range of m shapes becomes exactly m - 1 nodes: every
+// range knows the block of node indices it will fill before it is split (the
+// node itself, then the left subtree's block, then the right one's -- depth-first
+// order, whatever the schedule).  Ranges are therefore independent tasks, and a
+// few host threads share them for large scenes; the tree does not depend on how
+// many threads built it.
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <limits>
+#include <mutex>
+#include <thread>
 
 namespace {
 
 constexpr int BINS = 16;
 constexpr int SAH_DEPTH_LIMIT = 36;   // beyond this only median splits: depth <= 36 + log2(n)
+constexpr int SHARE_ABOVE = 4096;     // ranges larger than this may go to another thread
+constexpr int THREADS_MAX = 16;
 
 struct Box {
     float lo[3], hi[3];
@@ -37,7 +51,10 @@ struct Box {
     }
 };
 
-struct Task { int node, slot, begin, end, depth; };
+// The range [begin, end) of `order` becomes child `slot` of node `parent`
+// (parent < 0: the range is the whole scene and becomes node 0 itself); if it is
+// split, its own node is `node` and its subtree fills [node, node + count - 1).
+struct Task { int parent, slot, begin, end, node, depth; };
 
 // A node before its bounds are put on the grid.
 struct WideNode {
@@ -45,41 +62,31 @@ struct WideNode {
     int32_t child[2];
 };
 
-}  // namespace
+struct Builder {
+    const float* lo;
+    const float* hi;
+    const uint8_t* kind;
+    const float* centre;
+    int32_t* order;
+    WideNode* wide;
+    std::atomic<int> depth{0}, leaves{0};
 
-bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind, BvhBuild& out)
-{
-    if (n < 0 || n > (1 << 24)) return false;
-    // One shape per leaf: a shape test costs two to four node visits, and a lane
-    // testing a shape its neighbours do not idles them (grid of 97 k shapes: 384 /
-    // 373 / 359 / 342 Msamples/s at 1 / 2 / 3 / 4 shapes per leaf).
-    const int leaf_max = 1;
-    out.nodes.clear();
-    out.depth = 0;
-    out.leaves = 0;
-    std::vector<int32_t> order_v((size_t)n + 1);
-    for (int i = 0; i < n; i++) order_v[(size_t)i] = i;
-    std::vector<WideNode> wide;
-    std::vector<float> centre((size_t)n * 3);
-    for (size_t i = 0; i < (size_t)n * 3; i++) centre[i] = 0.5f * lo[i] + 0.5f * hi[i];
+    // work shared between threads
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Task> shared;
+    int busy = 0;          // threads holding work
+    bool sharing = false;
 
-    WideNode blank;
-    for (int k = 0; k < 3; k++) blank.lo[0][k] = blank.hi[0][k] = blank.lo[1][k] = blank.hi[1][k] = 0.0f;
-    blank.child[0] = blank.child[1] = ~3;           // leaves of nothing
-    wide.push_back(blank);
-
-    int32_t* order = order_v.data();
-    std::vector<Task> todo;
-    if (n <= 1) {
-        if (n > 0) todo.push_back({0, 0, 0, n, 1});
-    } else {
-        // the root's two children are made by splitting the whole range like any other
-        todo.push_back({-1, 0, 0, n, 0});
+    void note_depth(int d)
+    {
+        int cur = depth.load(std::memory_order_relaxed);
+        while (d > cur && !depth.compare_exchange_weak(cur, d, std::memory_order_relaxed)) {}
     }
 
-    while (!todo.empty()) {
-        const Task t = todo.back();
-        todo.pop_back();
+    // Bounds and leaf / node decision of one range; pushes the two halves on `local`.
+    void process(const Task& t, std::vector<Task>& local)
+    {
         const int count = t.end - t.begin;
         Box bounds, cbounds;
         bounds.clear();
@@ -87,14 +94,10 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind,
         for (int i = t.begin; i < t.end; i++) {
             const size_t s = (size_t)order[i];
             bounds.grow(lo + 3 * s, hi + 3 * s);
-            cbounds.grow(&centre[3 * s], &centre[3 * s]);
+            cbounds.grow(centre + 3 * s, centre + 3 * s);
         }
-
-        int self;   // the node whose children this range becomes, when it is split
-        if (t.node < 0) {
-            self = 0;
-        } else {
-            WideNode& parent = wide[(size_t)t.node];
+        if (t.parent >= 0) {
+            WideNode& parent = wide[(size_t)t.parent];
             for (int k = 0; k < 3; k++) {
                 parent.lo[t.slot][k] = bounds.lo[k];
                 parent.hi[t.slot][k] = bounds.hi[k];
@@ -102,13 +105,11 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind,
             if (count == 1) {
                 const int32_t s = order[t.begin];
                 parent.child[t.slot] = ~(s * 4 + (int32_t)kind[s]);
-                out.leaves++;
-                out.depth = std::max(out.depth, t.depth);
-                continue;
+                leaves.fetch_add(1, std::memory_order_relaxed);
+                note_depth(t.depth);
+                return;
             }
-            self = (int)wide.size();
-            wide[(size_t)t.node].child[t.slot] = self;
-            wide.push_back(blank);
+            parent.child[t.slot] = t.node;
         }
 
         // ---- choose the split
@@ -116,32 +117,41 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind,
         if (t.depth < SAH_DEPTH_LIMIT) {
             double best_cost = std::numeric_limits<double>::infinity();
             int best_axis = -1, best_bin = -1;
+            // one pass over the range fills the bins of all three axes
+            Box bin_box[3][BINS];
+            int bin_n[3][BINS];
+            double scale[3];
+            bool usable[3];
             for (int axis = 0; axis < 3; axis++) {
                 const float c0 = cbounds.lo[axis], c1 = cbounds.hi[axis];
-                if (!(c1 > c0)) continue;
-                const double scale = BINS / ((double)c1 - c0);
-                Box bin_box[BINS];
-                int bin_n[BINS];
-                for (int b = 0; b < BINS; b++) { bin_box[b].clear(); bin_n[b] = 0; }
-                for (int i = t.begin; i < t.end; i++) {
-                    const size_t s = (size_t)order[i];
-                    int b = (int)(((double)centre[3 * s + axis] - c0) * scale);
+                usable[axis] = c1 > c0;
+                scale[axis] = usable[axis] ? BINS / ((double)c1 - c0) : 0.0;
+                for (int b = 0; b < BINS; b++) { bin_box[axis][b].clear(); bin_n[axis][b] = 0; }
+            }
+            for (int i = t.begin; i < t.end; i++) {
+                const size_t s = (size_t)order[i];
+                for (int axis = 0; axis < 3; axis++) {
+                    if (!usable[axis]) continue;
+                    int b = (int)(((double)centre[3 * s + axis] - cbounds.lo[axis]) * scale[axis]);
                     b = std::min(std::max(b, 0), BINS - 1);
-                    bin_box[b].grow(lo + 3 * s, hi + 3 * s);
-                    bin_n[b]++;
+                    bin_box[axis][b].grow(lo + 3 * s, hi + 3 * s);
+                    bin_n[axis][b]++;
                 }
+            }
+            for (int axis = 0; axis < 3; axis++) {
+                if (!usable[axis]) continue;
                 double right_area[BINS];
                 Box acc;
                 acc.clear();
                 for (int b = BINS - 1; b > 0; b--) {
-                    acc.grow(bin_box[b]);
+                    acc.grow(bin_box[axis][b]);
                     right_area[b] = acc.half_area();
                 }
                 acc.clear();
                 int left_n = 0;
                 for (int b = 0; b < BINS - 1; b++) {
-                    acc.grow(bin_box[b]);
-                    left_n += bin_n[b];
+                    acc.grow(bin_box[axis][b]);
+                    left_n += bin_n[axis][b];
                     if (left_n == 0 || left_n == count) continue;
                     const double cost = acc.half_area() * left_n + right_area[b + 1] * (count - left_n);
                     if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
@@ -173,9 +183,92 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind,
                 return ca < cb || (ca == cb && a < b);
             });
         }
-        todo.push_back({self, 0, t.begin, mid, t.depth + 1});
-        todo.push_back({self, 1, mid, t.end, t.depth + 1});
+        const int left_count = mid - t.begin;
+        // the node, then the left subtree's left_count - 1 nodes, then the right subtree
+        local.push_back({t.node, 1, mid, t.end, t.node + left_count, t.depth + 1});
+        local.push_back({t.node, 0, t.begin, mid, t.node + 1, t.depth + 1});
     }
+
+    void worker()
+    {
+        std::vector<Task> local;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return !shared.empty() || busy == 0; });
+                if (shared.empty()) return;       // nothing queued and nobody could queue more
+                local.push_back(shared.back());
+                shared.pop_back();
+                busy++;
+            }
+            while (!local.empty()) {
+                const Task t = local.back();
+                local.pop_back();
+                process(t, local);
+                // hand the larger pending ranges to idle threads
+                if (sharing && local.size() > 1 && local.front().end - local.front().begin > SHARE_ABOVE) {
+                    std::lock_guard<std::mutex> lock(mu);
+                    shared.push_back(local.front());
+                    local.erase(local.begin());
+                    cv.notify_one();
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                busy--;
+                if (busy == 0) cv.notify_all();
+            }
+        }
+    }
+};
+
+}  // namespace
+
+bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind, BvhBuild& out)
+{
+    if (n < 0 || n > (1 << 24)) return false;
+    out.nodes.clear();
+    out.depth = 0;
+    out.leaves = 0;
+    std::vector<int32_t> order((size_t)n + 1);
+    for (int i = 0; i < n; i++) order[(size_t)i] = i;
+    std::vector<float> centre((size_t)n * 3 + 3);
+    for (size_t i = 0; i < (size_t)n * 3; i++) centre[i] = 0.5f * lo[i] + 0.5f * hi[i];
+
+    WideNode blank;
+    for (int k = 0; k < 3; k++) blank.lo[0][k] = blank.hi[0][k] = blank.lo[1][k] = blank.hi[1][k] = 0.0f;
+    blank.child[0] = blank.child[1] = ~3;           // leaves of nothing
+    std::vector<WideNode> wide((size_t)std::max(1, n - 1), blank);
+
+    Builder B;
+    B.lo = lo;
+    B.hi = hi;
+    B.kind = kind;
+    B.centre = centre.data();
+    B.order = order.data();
+    B.wide = wide.data();
+    if (n == 1) B.shared.push_back({0, 0, 0, 1, 0, 1});       // the root's only child is a leaf
+    else if (n > 1) B.shared.push_back({-1, 0, 0, n, 0, 0});  // the whole scene becomes node 0
+
+    int threads = 1;
+    if (n >= 4 * SHARE_ABOVE) {
+        threads = (int)std::thread::hardware_concurrency();
+        if (const char* e = std::getenv("OMP_NUM_THREADS")) {
+            const int v = std::atoi(e);
+            if (v > 0) threads = std::min(threads, v);
+        }
+        threads = std::max(1, std::min(threads, THREADS_MAX));
+    }
+    B.sharing = threads > 1;
+    if (threads == 1) {
+        B.worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; i++) pool.emplace_back([&B] { B.worker(); });
+        for (std::thread& th : pool) th.join();
+    }
+    out.depth = B.depth.load();
+    out.leaves = B.leaves.load();
     if (out.depth > PTK_BVH_STACK - 2) return false;
 
     // ---- the grid: 16 bits per axis over the bounds of everything
@@ -195,7 +288,8 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind,
         scale[k] = out.grid_scale[k];
     }
     out.nodes.resize(wide.size());
-    for (size_t i = 0; i < wide.size(); i++) {
+    ptk_parallel_for((int)wide.size(), [&](int i0, int i1) {
+    for (size_t i = (size_t)i0; i < (size_t)i1; i++) {
         const WideNode& w = wide[i];
         BvhNode& o = out.nodes[i];
         for (int c = 0; c < 2; c++)
@@ -210,5 +304,6 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind,
         o.child[0] = w.child[0];
         o.child[1] = w.child[1];
     }
+    });
     return true;
 }

@@ -2,10 +2,39 @@
 // the ptk_set_scene kernels walk (layout: BvhNode in ptk_dev.h).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "ptk_dev.h"
+
+// Runs fn(begin, end) over [0, n) in contiguous chunks on a few host threads
+// (one when n is small); fn must only write what belongs to its own indices.
+template <class Fn>
+void ptk_parallel_for(int n, Fn fn)
+{
+    int threads = 1;
+    if (n >= 32768) {
+        threads = (int)std::thread::hardware_concurrency();
+        if (const char* e = std::getenv("OMP_NUM_THREADS")) {
+            const int v = std::atoi(e);
+            if (v > 0) threads = std::min(threads, v);
+        }
+        threads = std::max(1, std::min(threads, 16));
+    }
+    if (threads == 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) {
+        const int b = (int)((int64_t)n * t / threads), e = (int)((int64_t)n * (t + 1) / threads);
+        pool.emplace_back([=] { fn(b, e); });
+    }
+    for (std::thread& th : pool) th.join();
+}
 
 struct BvhBuild {
     std::vector<BvhNode> nodes;   // nodes[0] is the root

@@ -1,6 +1,7 @@
 // ptk_api.cpp -- host side of libptk: context, HBM buffers, scene compilation,
 // seed generation, launches.  Everything here runs on the caller's thread;
 // device work is enqueued on one stream per context.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -485,9 +486,7 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     shapes.resize((size_t)n + 1);
     rot.assign(((size_t)n + 1) * 16, 0.0f);
     face_normal.assign(((size_t)n + 1) * 21, 0.0f);
-    std::vector<ScanRec> scan((size_t)n + 1);
     std::memset((void*)shapes.data(), 0, shapes.size() * sizeof(DevShape));
-    std::memset((void*)scan.data(), 0, scan.size() * sizeof(ScanRec));
     bool& has_blur = H.has_blur;
     bool& any_dielectric = H.any_dielectric;
     has_blur = any_dielectric = false;
@@ -507,8 +506,6 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
                 return fail(PTK_ERR_ARG, "shape %d: quaternion of squared length %g", s, q2);
         }
         const float* m = k->mat_list + (size_t)mat * 6;
-        compile_shape(type, mat, (int)m[5], at, shapes[(size_t)s], &rot[(size_t)s * 16],
-                      reinterpret_cast<float(*)[3]>(&face_normal[(size_t)s * 21]), scan[(size_t)s]);
         has_blur = has_blur || m[3] > 0.0f;
         any_dielectric = any_dielectric || (int)m[5] == 3;
         for (int i = 0; i < (type == 0 ? 3 : 9); i++) extent = std::max(extent, (double)std::fabs(at[i]));
@@ -518,6 +515,17 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     if (extent > 1e6)
         return fail(PTK_ERR_ARG, "ptk_set_scene: coordinates up to %g exceed 1e6", extent);
     H.extent = extent;
+    ptk_parallel_for(n, [&](int s0, int s1) {
+        for (int s = s0; s < s1; s++) {
+            const int mat = k->shape_mat[s];
+            ScanRec unused;     // the fixed-size kernels' record; these scenes use LeafRec
+            std::memset((void*)&unused, 0, sizeof unused);
+            compile_shape(k->shape_type[s], mat, (int)k->mat_list[(size_t)mat * 6 + 5],
+                          k->shape_attrs + (size_t)s * PTK_SCENE_ATTRS, shapes[(size_t)s],
+                          &rot[(size_t)s * 16],
+                          reinterpret_cast<float(*)[3]>(&face_normal[(size_t)s * 21]), unused);
+        }
+    });
 
     // ---- bounds.  A shape test accepts a ray only if the ray passes the shape
     // within the test's rounding error, which grows with the distances involved
@@ -532,7 +540,8 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     std::vector<float>& bhi = H.bhi;
     blo.assign((size_t)n * 3 + 3, 0.0f);
     bhi.assign((size_t)n * 3 + 3, 0.0f);
-    for (int s = 0; s < n; s++) {
+    ptk_parallel_for(n, [&](int s0, int s1) {
+    for (int s = s0; s < s1; s++) {
         const DevShape& o = shapes[(size_t)s];
         double lo[3], hi[3];
         if (o.type == 0) {
@@ -571,19 +580,22 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
             bhi[(size_t)s * 3 + i] = std::nextafter((float)hi[i], INFINITY);
         }
     }
+    });
     std::vector<uint8_t> kind((size_t)n + 1, 0);
     std::vector<LeafRec>& recs = H.recs;
     recs.resize((size_t)n + 1);
     std::memset((void*)recs.data(), 0, recs.size() * sizeof(LeafRec));
-    for (int s = 0; s < n; s++) {
-        const DevShape& o = shapes[(size_t)s];
-        kind[(size_t)s] = o.type == 0 ? 0 : (o.rotated ? 2 : 1);
-        LeafRec& r = recs[(size_t)s];
-        for (int i = 0; i < 3; i++) { r.c[i] = o.c[i]; r.lo[i] = o.lo[i]; }
-        r.rsq = o.rsq;
-        r.hi_x = o.hi[0]; r.hi_y = o.hi[1]; r.hi_z = o.hi[2];
-        r.same_mask = o.same_mask;
-    }
+    ptk_parallel_for(n, [&](int s0, int s1) {
+        for (int s = s0; s < s1; s++) {
+            const DevShape& o = shapes[(size_t)s];
+            kind[(size_t)s] = o.type == 0 ? 0 : (o.rotated ? 2 : 1);
+            LeafRec& r = recs[(size_t)s];
+            for (int i = 0; i < 3; i++) { r.c[i] = o.c[i]; r.lo[i] = o.lo[i]; }
+            r.rsq = o.rsq;
+            r.hi_x = o.hi[0]; r.hi_y = o.hi[1]; r.hi_z = o.hi[2];
+            r.same_mask = o.same_mask;
+        }
+    });
     BvhBuild& bvh = H.bvh;
     if (!ptk_build_bvh(n, blo.data(), bhi.data(), kind.data(), bvh))
         return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of depth %d exceeds the traversal stack",
