@@ -141,10 +141,18 @@ int ensure_image(ptk_ctx* c, int width, int height)
     c->height = height;
     c->pixels = (size_t)width * (size_t)height;
     const size_t P = c->pixels;
-    HIP_TRY(hipMalloc((void**)&c->planes_d, PTK_N_PLANES * P * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&c->variances_d, 7 * P * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&c->denoised_d, 3 * P * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&c->wcsum_d, P * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&c->planes_d, PTK_N_PLANES * P * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->variances_d, 7 * P * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->denoised_d, 3 * P * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->wcsum_d, P * sizeof(float));
+    if (e != hipSuccess) {
+        free_image_buffers(c);
+        c->width = c->height = 0;
+        c->pixels = 0;
+        c->have_scene = false;
+        return fail(PTK_ERR_NOMEM, "allocating %dx%d image planes: %s", width, height,
+                    hipGetErrorString(e));
+    }
     return PTK_OK;
 }
 
@@ -395,6 +403,7 @@ int ptk_set_constants(ptk_ctx* c, const void* constants, size_t nbytes, int want
     if ((rc = ensure_image(c, k.res_h, k.res_v)) != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_big_scene(c);
+    c->have_scene = false;   // until the new scene is complete on the device
     c->host_scene = d;
     c->max_depth = k.max_depth;
     c->features = feats != 0;
@@ -715,6 +724,7 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     if ((rc = ensure_image(c, k->res_h, k->res_v)) != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_big_scene(c);
+    c->have_scene = false;   // until the new scene is complete on the device
 
     const void* src[7] = {bvh.nodes.data(), recs.data(), rot.data(), face_normal.data(),
                           shapes.data(), k->mat_list, imp.data()};
@@ -815,7 +825,8 @@ int ptk_set_stream_id(ptk_ctx* c, uint64_t stream_id)
 int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_t* rays_out)
 {
     if (!c) return fail(PTK_ERR_ARG, "ptk_render: null context");
-    if (!c->have_scene) return fail(PTK_ERR_STATE, "ptk_render before ptk_set_constants");
+    if (!c->have_scene || !c->planes_d)
+        return fail(PTK_ERR_STATE, "ptk_render before ptk_set_constants / ptk_set_scene succeeded");
     if (spp < 0) return fail(PTK_ERR_ARG, "ptk_render: spp %d < 0", spp);
     if (seed_mode != PTK_SEED_REFERENCE && seed_mode != PTK_SEED_COUNTER)
         return fail(PTK_ERR_ARG, "ptk_render: unknown seed mode %d", seed_mode);
