@@ -39,7 +39,7 @@ struct alignas(64) ScanRec {
     float c[3], lo[3], hi[3];
     float rsq;
     int32_t type, rotated, same_mask, mat_type, mat;
-    int32_t pad;
+    int32_t index;   // the shape's index, in the in-register copies the hierarchy walks make; 0 in DevScene::scan
 };
 static_assert(sizeof(ScanRec) == 64, "ScanRec must be 16 dwords");
 
