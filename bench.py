@@ -213,6 +213,11 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libptk has no CPU path")
+    # stdout carries the result line alone: whatever libraries print on the way (the collective
+    # library writes a version banner to file descriptor 1) is sent to stderr instead
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     gpu = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     device = torch.device("cuda", gpu)
@@ -340,7 +345,7 @@ def main():
                 out["scene_hierarchy"] = hierarchy_probe(ctx, W, H)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     ctx.close()
     if use_dist:
         dist.barrier(device_ids=[gpu]) if args.backend == "nccl" else dist.barrier()
