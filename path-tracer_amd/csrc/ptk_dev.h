@@ -27,7 +27,7 @@ struct DevShape {
     int32_t mat_type;  // (int)mat_list[mat][5]
     int32_t rotated;   // q.x + q.y + q.z > 1e-5f
     int32_t flat_axis; // first axis with |lo-hi| < 1e-5f, or -1
-    int32_t same_mask; // bit k set when lo[k] == hi[k] exactly (both slab quotients coincide)
+    int32_t same_mask; // bit k set when lo[k] == hi[k] exactly (not read by the kernels)
     int32_t pad[3];
 };
 static_assert(sizeof(DevShape) == 25 * 4, "DevShape must be 25 dwords");
