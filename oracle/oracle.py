@@ -120,6 +120,10 @@ def lib():
                                        C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_int,
                                        C.POINTER(C.c_uint64)]
         L.orc_render_scene.restype = C.c_int
+        L.orc_render_scene_pixels.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int,
+                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_int64), fp, C.c_int]
+        L.orc_render_scene_pixels.restype = C.c_int
         L.orc_auto_exposure.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(C.c_double)]
         L.orc_auto_exposure.restype = C.c_float
@@ -209,11 +213,8 @@ def render(consts, acc, spp, sample_count, glo, threads=1):
     return sc.value, (int(st[0]), int(st[1])), int(rays.value)
 
 
-def render_scene(scene, acc, spp, sample_count, glo, want_features=False, threads=1):
-    """As render(), over a scene dict with tables of any length: cam_pos, cam_forward,
-    cam_right, cam_up, rand_samp, max_depth, res_v, res_h, max_angle_v, max_angle_h,
-    focal_length, shape_type [N], shape_mat [N], shape_attrs [N,13], mat_list [M,6],
-    important_shapes [K]."""
+def _scene_desc(scene):
+    """Scene dict -> (orc_scene_desc, arrays it points into)."""
     d = SceneDesc()
     for k in ("cam_pos", "cam_forward", "cam_right", "cam_up"):
         getattr(d, k)[:] = [float(v) for v in scene[k]]
@@ -232,6 +233,15 @@ def render_scene(scene, acc, spp, sample_count, glo, want_features=False, thread
     d.shape_attrs = sa.ctypes.data_as(C.POINTER(C.c_float))
     d.mat_list = ml.ctypes.data_as(C.POINTER(C.c_float))
     d.important_shapes = im.ctypes.data_as(C.POINTER(C.c_uint32))
+    return d, (st, sm, sa, ml, im)
+
+
+def render_scene(scene, acc, spp, sample_count, glo, want_features=False, threads=1):
+    """As render(), over a scene dict with tables of any length: cam_pos, cam_forward,
+    cam_right, cam_up, rand_samp, max_depth, res_v, res_h, max_angle_v, max_angle_h,
+    focal_length, shape_type [N], shape_mat [N], shape_attrs [N,13], mat_list [M,6],
+    important_shapes [K]."""
+    d, keep = _scene_desc(scene)
     sc = C.c_int(sample_count)
     state = (C.c_uint64 * 2)(glo[0], glo[1])
     rays = C.c_uint64(0)
@@ -239,6 +249,23 @@ def render_scene(scene, acc, spp, sample_count, glo, want_features=False, thread
                                 state, threads, C.byref(rays))
     assert rc == 0
     return sc.value, (int(state[0]), int(state[1])), int(rays.value)
+
+
+def render_scene_pixels(scene, rows, cols, seeds, want_features=False, threads=1):
+    """One sample of each listed pixel: seeds (n, 2) int64.  Returns (n, 17) float32: colour,
+    normal, albedo1, albedo2, worldPos, directLight, rays."""
+    d, keep = _scene_desc(scene)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64).reshape(-1, 2)
+    assert len(rows) == len(cols) == len(seeds)
+    out = np.zeros((len(rows), 17), np.float32)
+    i32 = C.POINTER(C.c_int32)
+    rc = lib().orc_render_scene_pixels(C.byref(d), 1 if want_features else 0, len(rows),
+                                       rows.ctypes.data_as(i32), cols.ctypes.data_as(i32),
+                                       seeds.ctypes.data_as(C.POINTER(C.c_int64)), _fp(out), threads)
+    assert rc == 0
+    return out
 
 
 def auto_exposure(acc, width, height, sample_count, formula=0):

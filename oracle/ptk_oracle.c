@@ -779,6 +779,56 @@ int orc_render_scene(const orc_scene_desc* k, int want_features, float* acc, int
     return 0;
 }
 
+/* One sample of each listed pixel of such a scene (for spot checks of frames too large to
+ * recompute whole): out receives 17 floats per pixel -- colour, normal, albedo1, albedo2,
+ * worldPos, directLight, rays. */
+int orc_render_scene_pixels(const orc_scene_desc* k, int want_features, int n, const int32_t* rows,
+                            const int32_t* cols, const int64_t* seeds, float* out, int threads)
+{
+    if (k->num_shapes < 0 || n < 0) return -1;
+    int32_t (*shapes)[3] = malloc(sizeof(int32_t[3]) * (size_t)(k->num_shapes + 1));
+    if (!shapes) return -1;
+    for (int s = 0; s < k->num_shapes; s++) {
+        shapes[s][0] = k->shape_type[s];
+        shapes[s][1] = k->shape_mat[s];
+        shapes[s][2] = 13 * s;
+    }
+    scene_view v;
+    memcpy(v.cam_pos, k->cam_pos, sizeof v.cam_pos);
+    memcpy(v.cam_fwd, k->cam_forward, sizeof v.cam_fwd);
+    memcpy(v.cam_right, k->cam_right, sizeof v.cam_right);
+    memcpy(v.cam_up, k->cam_up, sizeof v.cam_up);
+    v.rand_samp = k->rand_samp;
+    v.num_shapes = k->num_shapes; v.max_depth = k->max_depth;
+    v.res_v = k->res_v; v.res_h = k->res_h;
+    v.max_angle_v = k->max_angle_v; v.max_angle_h = k->max_angle_h;
+    v.focal_length = k->focal_length;
+    v.shapes = (const int32_t (*)[3])shapes;
+    v.attrs = k->shape_attrs;
+    v.mats = (const float (*)[6])k->mat_list;
+    v.imp = k->important_shapes;
+    v.num_imp = (uint32_t)k->num_important_shapes;
+    v.want_features = want_features ? 1u : 0u;
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+#endif
+    for (int i = 0; i < n; i++) {
+        orc_sample s;
+        render_sample_view(&v, rows[i], cols[i], seeds[2 * i], seeds[2 * i + 1], &s);
+        float* o = out + 17 * (size_t)i;
+        memcpy(o, s.xyz, 3 * sizeof(float));
+        memcpy(o + 3, s.normal, 3 * sizeof(float));
+        memcpy(o + 6, s.albedo1, 3 * sizeof(float));
+        memcpy(o + 9, s.albedo2, 3 * sizeof(float));
+        memcpy(o + 12, s.world_pos, 3 * sizeof(float));
+        o[15] = s.direct_light;
+        o[16] = (float)s.rays_sent;
+    }
+    free(shapes);
+    return 0;
+}
+
 static void render_view(const scene_view* c, float* acc, int spp, int* sample_count,
                         uint64_t glo[2], int threads, uint64_t* rays_last_pass)
 {

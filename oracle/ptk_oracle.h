@@ -114,6 +114,12 @@ typedef struct {
 int orc_render_scene(const orc_scene_desc* scene, int want_features, float* acc, int spp,
                      int* sample_count, uint64_t glo[2], int threads, uint64_t* rays_last_pass);
 
+/* One sample of each listed pixel of such a scene; seeds holds (s1, s2) per pixel, out 17
+ * floats per pixel: colour, normal, albedo1, albedo2, worldPos, directLight, rays. */
+int orc_render_scene_pixels(const orc_scene_desc* scene, int want_features, int n,
+                            const int32_t* rows, const int32_t* cols, const int64_t* seeds,
+                            float* out, int threads);
+
 /* formula 0: CPUAutoExp as written; 1: SkePUAutoExp as written; 2: 9.6 * mean. */
 float orc_auto_exposure(const float* acc, int width, int height, int sample_count,
                         int formula, double* raw_sum);

@@ -102,6 +102,32 @@ def test_against_index_order_scan_on_cpu(ctx, oracle, n, dielectric):
     assert abs(gpu[0:3].mean() - acc[0:3].mean()) <= 2e-3 * acc[0:3].mean()
 
 
+def test_full_size_frame_spot_checked_against_the_cpu(ctx, oracle):
+    """1920x1080, 20 000 shapes with glass, the reference's sequential seed stream: one pass on
+    the GPU through the hierarchy; 3000 pixels drawn at random are recomputed on the CPU by the
+    index-order scan over all 20 000 shapes from the same seeds.  Same bar as the small frames."""
+    import ptk
+    import scenes
+    O = oracle
+    W, H = 1920, 1080
+    P = W * H
+    sc = scenes.random_scene(20000, W, H, seed=77)
+    stats = ctx.set_scene(sc, want_features=1)
+    assert stats["leaves"] == 20000
+    rays, glo = ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    gpu = ctx.read_planes(0, 16)
+    seeds, glo_o = O.seed_stream(PIN_SEED, P)
+    assert glo == glo_o
+    picks = np.sort(np.random.default_rng(3).choice(P, 3000, replace=False))
+    ref = O.render_scene_pixels(sc, picks // W, picks % W, seeds[picks], want_features=True,
+                                threads=8)
+    got = gpu[:, picks].T
+    same = ((got == ref[:, :16]) | (np.isnan(got) & np.isnan(ref[:, :16]))).all(axis=1)
+    assert same.mean() >= 0.99
+    first_hit = (got[:, 3:15] == ref[:, 3:15]).all(axis=1)
+    assert first_hit.mean() >= 0.999
+
+
 def test_tables_beyond_every_pod_limit(ctx, oracle):
     """More than 50 shapes, more than 127 materials (the fixed-size kernel's record
     holds 7 bits), more than 10 important shapes, at once."""
