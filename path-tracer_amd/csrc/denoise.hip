@@ -246,7 +246,12 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
 #pragma unroll
             for (int nd = 0; nd < 10; nd++)
                 a1[nd] = __builtin_fmaf(mad[k], w[70 * k + 60 + nd], a1[nd]);
-            if (features_out) features_out[(size_t)(30 + k) * P + idx] = mad[k];
+        }
+        // one branch after all five: a conditional store per channel would split the
+        // chains above into five blocks, one after the other
+        if (features_out) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) features_out[(size_t)(30 + k) * P + idx] = mad[k];
         }
     }
 
