@@ -51,3 +51,47 @@ def test_missing_files_are_reported(tmp_path):
         ptk.resave_scene(str(tmp_path / "nope.scene"), str(tmp_path / "x"))
     with pytest.raises(ptk.PtkError):
         ptk.load_weights(str(tmp_path / "nope.txt"))
+
+
+def test_scene_file_beyond_the_pod_keeps_every_shape(tmp_path):
+    """A .scene file of 300 shapes, 70 materials and 14 important shapes: the POD the facade fills
+    stops at the reference's limits, the tables it hands to ptk_set_scene hold everything, the
+    hierarchy built for them verifies, and the file survives a save and reload."""
+    import ptk
+    rng = np.random.default_rng(8)
+    lines = ["m %.3f/%.3f/%.3f 0 1 %d" % (*rng.uniform(0.2, 0.9, 3), 1 if k < 14 else 0)
+             for k in range(70)]
+    for k in range(300):
+        c = rng.uniform(-8, 8, 3)
+        if k % 2:
+            lines += ["o 0", "d %.4f/%.4f/%.4f %.4f %d" % (c[0], c[1], c[2], rng.uniform(0.1, 0.5), k % 70)]
+        else:
+            h = rng.uniform(0.1, 0.6, 3)
+            r = rng.uniform(0, 3, 3) if k % 4 == 0 else np.zeros(3)
+            lines += ["o 1", "d %.4f/%.4f/%.4f %.4f/%.4f/%.4f %.4f/%.4f/%.4f %.3f/%.3f/%.3f %d" % (
+                c[0], c[1], c[2], -h[0], -h[1], -h[2], h[0], h[1], h[2], r[0], r[1], r[2], k % 70)]
+    lines += ["i %d" % k for k in range(14)]
+    lines += ["c 0/0/-12 0/0/1 0/1/0 1/0/0 90 120", "pp 2.5 2.2"]
+    path = str(tmp_path / "big.scene")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+    raw, exposure, gamma = ptk.scene_constants(path, 64, 36)
+    pod = ptk.scene_from_constants(raw)
+    assert len(pod["shape_type"]) < 300 and len(pod["important_shapes"]) == 10
+    scene, e2, g2 = ptk.scene_tables(path, 64, 36)
+    assert (e2, g2) == (exposure, gamma) and abs(exposure - 2.5) < 1e-6
+    assert len(scene["shape_type"]) == 300 and len(scene["mat_list"]) == 70
+    assert list(scene["important_shapes"]) == list(range(14))
+    n_pod = len(pod["shape_type"])
+    assert np.array_equal(scene["shape_attrs"][:n_pod], pod["shape_attrs"])
+    assert np.array_equal(scene["shape_mat"][:n_pod], pod["shape_mat"])
+    stats = ptk.check_scene(scene)
+    assert stats["leaves"] == 300
+
+    again = str(tmp_path / "again.scene")
+    ptk.resave_scene(path, again)
+    scene2, _, _ = ptk.scene_tables(again, 64, 36)
+    for key in ("shape_type", "shape_mat", "mat_list", "important_shapes"):
+        assert np.array_equal(scene[key], scene2[key])
+    assert np.allclose(scene["shape_attrs"], scene2["shape_attrs"], rtol=0, atol=2e-4)
