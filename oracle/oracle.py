@@ -80,26 +80,59 @@ class Scene(C.Structure):
     ]
 
 
-def build(force=False):
-    """Compile the oracle with gcc (a few seconds)."""
+_VARIANT_LIBS = {"F": "libptk_oracle.so", "D": "libptk_oracle_D.so", "R": "libptk_oracle_R.so"}
+
+
+def build(force=False, variant="F"):
+    """Compile one variant of the oracle with gcc (a few seconds).
+
+    F: unqualified libm calls bind to the float overloads (canonical).
+    D: they bind to the C double functions (what a g++/<cmath> build does).
+    R: as F with cos/sin/acos/pow correctly rounded (evaluated in double, rounded once).
+    """
+    name = _VARIANT_LIBS[variant]
+    path = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "ptk_oracle.c")
     hdr = os.path.join(_HERE, "ptk_oracle.h")
-    if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
-        return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-B", "libptk_oracle.so"],
-                          stdout=subprocess.DEVNULL)
-    return _LIB_PATH
+    if (not force and os.path.exists(path)
+            and os.path.getmtime(path) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return path
+    subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
+    return path
 
 
-_lib = None
+_libs = {}
+_variant = "F"
+
+
+class variant:
+    """Context manager: route every call of this module to another libm variant of the
+    oracle ("F", "D" or "R"; see build())."""
+
+    def __init__(self, name):
+        assert name in _VARIANT_LIBS
+        self.name = name
+
+    def __enter__(self):
+        global _variant
+        self.prev, _variant = _variant, self.name
+        lib()
+        return self
+
+    def __exit__(self, *exc):
+        global _variant
+        _variant = self.prev
+        return False
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+    if _variant not in _libs:
+        _libs[_variant] = _bind(C.CDLL(build(variant=_variant)))
+    return _libs[_variant]
+
+
+def _bind(L):
+    if True:
         fp = C.POINTER(C.c_float)
         L.orc_load_scene.argtypes = [C.c_char_p, C.POINTER(Scene)]
         L.orc_load_scene.restype = C.c_int
@@ -152,8 +185,7 @@ def lib():
         L.orc_post_process.restype = C.c_int
         L.orc_quantise8.argtypes = [fp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         L.orc_quantise8.restype = None
-        _lib = L
-    return _lib
+    return L
 
 
 def _fp(a):

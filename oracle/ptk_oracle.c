@@ -25,8 +25,24 @@
  * binds to depends on the headers in scope of its build: the float overloads
  * (variant F, the default here and the canonical one) or the C double
  * functions (variant D, -DORC_LIBM_DOUBLE).  Only the render path honours the
- * switch; it exists to measure the gap between the two builds. */
-#ifdef ORC_LIBM_DOUBLE
+ * switch; it exists to measure the gap between the two builds.
+ *
+ * Variant R (-DORC_LIBM_ROUNDED) is variant F with cos/sin/acos/pow replaced by
+ * their correctly rounded float results: evaluated in double (glibc's double
+ * functions are within one double ulp) and rounded to float once.  glibc's
+ * cosf/sinf/acosf/powf are only faithfully rounded, so variant F can differ
+ * from it by one float ulp at those four calls and nowhere else.  A second
+ * implementation that rounds those calls correctly -- as the HIP path does --
+ * must equal variant R bit for bit on every sample. */
+#if defined(ORC_LIBM_ROUNDED)
+typedef float lm_t;
+#define LM_SQRT(x) sqrtf(x)
+#define LM_COS(x) ((float)cos((double)(x)))
+#define LM_SIN(x) ((float)sin((double)(x)))
+#define LM_ACOS(x) ((float)acos((double)(x)))
+#define LM_POW(x, y) ((float)pow((double)(x), (double)(y)))
+#define LM_EXP(x) expf(x)
+#elif defined(ORC_LIBM_DOUBLE)
 typedef double lm_t;
 #define LM_SQRT(x) sqrt((double)(x))
 #define LM_COS(x) cos((double)(x))

@@ -1,4 +1,6 @@
-"""Regenerates tests/golden/*.npz from the CPU oracle (canonical variant F).
+"""Regenerates tests/golden/*.npz from the CPU oracle (canonical variant F, plus the
+render results of variant R: cos/sin/acos/pow correctly rounded, which an implementation
+that rounds those four calls correctly must reproduce bit for bit).
 
 The reference ships no golden vectors and cannot be built in this image, so
 these fixtures are outputs of the pinned oracle (see tests/test_oracle_pins.py
@@ -22,6 +24,21 @@ SEED = (0x9E3779B97F4A7C15, 0xD1B54A32D192ED03)
 SCENES = ["cornell", "cornell_crystal", "MultiLightGlass", "Box_Grid", "blur_test", "bars3"]
 
 
+def one_sample_per_pixel(consts, pix, W, H):
+    """(P, 17): xyz, normal, albedo1, albedo2, worldPos, directLight, rays of one sample."""
+    samples = np.zeros((H * W, 17), dtype=np.float32)
+    for idx in range(W * H):
+        s = O.render_sample(consts, idx // W, idx % W, int(pix[idx, 0]), int(pix[idx, 1]))
+        samples[idx, 0:3] = s.xyz
+        samples[idx, 3:6] = s.normal
+        samples[idx, 6:9] = s.albedo1
+        samples[idx, 9:12] = s.albedo2
+        samples[idx, 12:15] = s.world_pos
+        samples[idx, 15] = s.direct_light
+        samples[idx, 16] = s.rays_sent
+    return samples
+
+
 def main():
     # (i) RNG known answers: first 64 pixel seeds, first 64 draws of pixel 0
     seeds, state = O.seed_stream(SEED, 64)
@@ -37,23 +54,20 @@ def main():
         sc = O.load_scene(os.path.join(ROOT, "data", "scenes", name + ".scene"))
         consts = O.build_constants(sc, W, H, 4, 0.005, True)
         pix, _ = O.seed_stream(SEED, W * H)
-        samples = np.zeros((H * W, 17), dtype=np.float32)
-        for idx in range(W * H):
-            s = O.render_sample(consts, idx // W, idx % W, int(pix[idx, 0]), int(pix[idx, 1]))
-            samples[idx, 0:3] = s.xyz
-            samples[idx, 3:6] = s.normal
-            samples[idx, 6:9] = s.albedo1
-            samples[idx, 9:12] = s.albedo2
-            samples[idx, 12:15] = s.world_pos
-            samples[idx, 15] = s.direct_light
-            samples[idx, 16] = s.rays_sent
+        samples = one_sample_per_pixel(consts, pix, W, H)
         acc = O.new_accumulators(W, H)
         n, glo, rays = O.render(consts, acc, 8, 0, SEED, threads=4)
         exps = [O.auto_exposure(acc, W, H, n, f)[0] for f in (0, 1, 2)]
         raw = O.auto_exposure(acc, W, H, n, 0)[1]
+        with O.variant("R"):
+            samples_r = one_sample_per_pixel(consts, pix, W, H)
+            acc_r = O.new_accumulators(W, H)
+            n_r, glo_r, rays_r = O.render(consts, acc_r, 8, 0, SEED, threads=4)
+            assert n_r == n and glo_r == glo
         np.savez_compressed(os.path.join(OUT, "render_%s_64x36.npz" % name),
                             constants=np.frombuffer(bytes(consts), dtype=np.uint8),
                             samples_1spp=samples, acc_8spp=acc, sample_count=n,
+                            samples_1spp_R=samples_r, acc_8spp_R=acc_r, rays_last_R=rays_r,
                             glo_after=np.array(glo, dtype=np.uint64), rays_last=rays,
                             exposure=np.array(exps, dtype=np.float32), raw_sum=raw)
 

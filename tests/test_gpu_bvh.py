@@ -14,8 +14,10 @@ What is checked, and to what bar:
   * Against the CPU checker's index-order scan over the same tables
     (orc_render_scene: the reference's per-sample function with the 50-shape
     limit lifted -- "parity unpinned" beyond 50 shapes, since the reference
-    cannot hold such a scene): >= 99 % of pixels bit-identical per sample, the
-    same bar and for the same reason (libm rounding) as test_gpu_parity.py.
+    cannot hold such a scene): >= 99 % of pixels bit-identical per sample to the
+    canonical build (glibc's faithfully rounded cosf/sinf/acosf/powf), and EVERY
+    plane of EVERY pixel bit-identical to the build with those four calls
+    correctly rounded (variant R) -- the same two bars as test_gpu_parity.py.
 """
 import numpy as np
 import pytest
@@ -100,6 +102,10 @@ def test_against_index_order_scan_on_cpu(ctx, oracle, n, dielectric):
     close = np.abs(gpu[0:3].astype(np.float64) - acc[0:3]) <= 1e-4 * np.abs(acc[0:3]) + 1e-7
     assert close.all(axis=0).mean() >= 0.97
     assert abs(gpu[0:3].mean() - acc[0:3].mean()) <= 2e-3 * acc[0:3].mean()
+    with oracle.variant("R"):
+        acc_r = oracle.new_accumulators(W, H)
+        oracle.render_scene(sc, acc_r, 5, 0, PIN_SEED, want_features=True, threads=8)
+    assert _same(gpu, acc_r).all()
 
 
 def test_full_size_frame_spot_checked_against_the_cpu(ctx, oracle):
@@ -126,6 +132,10 @@ def test_full_size_frame_spot_checked_against_the_cpu(ctx, oracle):
     assert same.mean() >= 0.99
     first_hit = (got[:, 3:15] == ref[:, 3:15]).all(axis=1)
     assert first_hit.mean() >= 0.999
+    with O.variant("R"):
+        ref_r = O.render_scene_pixels(sc, picks // W, picks % W, seeds[picks], want_features=True,
+                                      threads=8)
+    assert _same(got, ref_r[:, :16]).all()
 
 
 def test_tables_beyond_every_pod_limit(ctx, oracle):
@@ -148,6 +158,10 @@ def test_tables_beyond_every_pod_limit(ctx, oracle):
     assert glo == glo_o
     assert _same(gpu[0:3], acc[0:3]).all(axis=0).mean() >= 0.98
     assert _same(gpu[6:9], acc[6:9]).all(axis=0).mean() >= 0.995    # first-hit albedo: the material
+    with oracle.variant("R"):
+        acc_r = oracle.new_accumulators(W, H)
+        oracle.render_scene(sc, acc_r, 2, 0, PIN_SEED, want_features=True, threads=8)
+    assert _same(gpu, acc_r).all()
 
 
 @pytest.mark.parametrize("n", [0, 1, 3, 5])
@@ -163,6 +177,10 @@ def test_tiny_scenes(ctx, oracle, n):
     acc = oracle.new_accumulators(W, H)
     oracle.render_scene(sc, acc, 2, 0, PIN_SEED, threads=1)
     assert _same(gpu, acc[0:3]).all(axis=0).mean() >= 0.99
+    with oracle.variant("R"):
+        acc_r = oracle.new_accumulators(W, H)
+        oracle.render_scene(sc, acc_r, 2, 0, PIN_SEED, threads=1)
+    assert _same(gpu, acc_r[0:3]).all()
     if n == 0:
         assert rays == 2 * W * H     # every path is one ray into the sky
 

@@ -3,18 +3,20 @@ committed golden fixtures.
 
 Tolerances (PTK_MATH_EXACT, matched reference seeds).  The kernel performs the
 reference's fp32 operations in the reference's order with IEEE divide/sqrt and
-no FMA contraction; the only places it cannot be bit-identical to the oracle
-are cosf/sinf/acosf/powf, where glibc is faithfully (not correctly) rounded.
-A one-ulp difference there perturbs a path's colour by ~1e-7 relative, and on
-rare paths flips a discrete decision (closest shape, refract/reflect, shadow
-test), after which that sample is a different, equally valid path.  Hence:
+no FMA contraction, and evaluates cos/sin/acos and the Schlick power in double,
+rounding once.  The oracle has two builds to compare with:
 
-  * RNG streams, ray counts, seed state: bit-exact.
-  * 1 spp: >= 99 % of pixels bit-identical in colour, >= 99.9 % within 1e-4
-    relative; first-hit feature planes identical on >= 99.9 % of pixels.
-  * 8 spp accumulators: >= 99.5 % of pixels within 1e-4 relative; image mean
-    within 1e-4 relative (the libm-variant noise floor of the reference itself
-    is 6e-5).
+  * variant R (cos/sin/acos/pow correctly rounded): the kernel must equal it BIT
+    FOR BIT -- every pixel, every sample, all 38 planes, NaN for NaN.
+  * variant F (glibc's cosf/sinf/acosf/powf, faithfully but not correctly
+    rounded; the canonical build): a one-ulp difference at one of those calls
+    perturbs a path's colour by ~1e-7 relative and on rare paths flips a
+    discrete decision (closest shape, refract/reflect, shadow test), after
+    which that sample is a different, equally valid path.  Against F: >= 99 %
+    of pixels bit-identical in colour at 1 spp, >= 99.9 % within 1e-4
+    relative; 8 spp accumulators >= 99.5 % within 1e-4 and the image mean
+    within 1e-4 (the libm-variant noise floor of the reference itself is 6e-5).
+  * RNG streams, ray counts, seed state: bit-exact against both.
   * exposure: raw sum within 1e-9 relative of the oracle's double sum, scaled
     value within 2e-6 relative of the oracle's sequential-fp32 value at these
     sizes.
@@ -96,6 +98,34 @@ def test_eight_samples_match_golden_accumulators(ctx, name, oracle):
         assert abs(e_gpu - e_ref) <= 2e-6 * abs(e_ref)
 
 
+def _mismatch_report(got, ref, W):
+    bad = ~_same(got, ref)
+    if not bad.any():
+        return ""
+    planes, pixels = np.nonzero(bad)
+    first = ["plane %d pixel (row %d, col %d): %r vs %r" % (p, i // W, i % W, got[p, i], ref[p, i])
+             for p, i in list(zip(planes, pixels))[:8]]
+    return "%d values in %d pixels differ; first: %s" % (bad.sum(), len(set(pixels)),
+                                                         "; ".join(first))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_exact_mode_equals_the_rounded_libm_oracle_bit_for_bit(ctx, name):
+    """Against variant R of the oracle (cos/sin/acos/pow correctly rounded) nothing may
+    differ: one sample, then eight, all planes of every pixel."""
+    import ptk
+    g = np.load(os.path.join(GOLDEN, "render_%s_64x36.npz" % name))
+    ctx.set_math_mode(ptk.MATH_EXACT)
+    ctx.set_constants(g["constants"].tobytes())
+    rays, glo = ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    ref = g["samples_1spp_R"]
+    assert rays == int(ref[:, 16].sum())
+    assert _mismatch_report(ctx.read_planes(0, 16), np.ascontiguousarray(ref[:, 0:16].T), 64) == ""
+    rays7, glo = ctx.render(7, ptk.SEED_REFERENCE, glo)
+    assert glo == tuple(int(x) for x in g["glo_after"])
+    assert _mismatch_report(ctx.read_planes(), g["acc_8spp_R"], 64) == ""
+
+
 def test_read_accumulators_uses_the_reference_layout(ctx):
     import ptk
     g = np.load(os.path.join(GOLDEN, "render_cornell_64x36.npz"))
@@ -169,6 +199,10 @@ def test_render_odd_sizes_depths_and_empty_scene(ctx, oracle):
         assert gglo == glo
         planes = ctx.read_planes()
         assert _rel_ok(planes, acc, 1e-4).all(axis=0).mean() >= 0.98
+        with O.variant("R"):
+            acc_r = O.new_accumulators(W, H)
+            O.render(consts, acc_r, 2, 0, PIN_SEED, threads=2)
+        assert _mismatch_report(planes, acc_r, W) == ""
     # no shapes: every ray misses and sees the sky gradient
     consts = O.build_constants(sc, 32, 16, 4, 0.0, False)
     consts.num_shapes = 0
@@ -258,20 +292,28 @@ def test_full_size_frame_spot_checked_against_the_cpu(ctx, oracle, name):
     assert glo2 == glo_end
     rng = np.random.default_rng(5)
     picks = rng.choice(P, 4000, replace=False)
-    same1 = same2 = 0
-    for i in picks:
-        row, col = divmod(int(i), W)
-        s = O.render_sample(consts, row, col, int(seeds1[i, 0]), int(seeds1[i, 1]))
-        ref1 = np.float32(list(s.xyz) + list(s.normal) + list(s.albedo1) + list(s.albedo2)
-                          + list(s.world_pos) + [s.direct_light])
-        ok1 = np.array_equal(first[:, i], ref1, equal_nan=True)
-        same1 += ok1
-        s = O.render_sample(consts, row, col, int(seeds2[i, 0]), int(seeds2[i, 1]))
-        ref2 = np.float32(list(s.xyz) + list(s.normal) + list(s.albedo1) + list(s.albedo2)
-                          + list(s.world_pos) + [s.direct_light])
-        same2 += ok1 and np.array_equal(both[:, i], ref1 + ref2, equal_nan=True)
+
+    def recompute():
+        same1 = same2 = 0
+        for i in picks:
+            row, col = divmod(int(i), W)
+            s = O.render_sample(consts, row, col, int(seeds1[i, 0]), int(seeds1[i, 1]))
+            ref1 = np.float32(list(s.xyz) + list(s.normal) + list(s.albedo1) + list(s.albedo2)
+                              + list(s.world_pos) + [s.direct_light])
+            ok1 = np.array_equal(first[:, i], ref1, equal_nan=True)
+            same1 += ok1
+            s = O.render_sample(consts, row, col, int(seeds2[i, 0]), int(seeds2[i, 1]))
+            ref2 = np.float32(list(s.xyz) + list(s.normal) + list(s.albedo1) + list(s.albedo2)
+                              + list(s.world_pos) + [s.direct_light])
+            same2 += ok1 and np.array_equal(both[:, i], ref1 + ref2, equal_nan=True)
+        return same1, same2
+
+    same1, same2 = recompute()            # canonical variant F: libm-limited
     assert same1 >= 0.99 * len(picks)
     assert same2 >= 0.98 * len(picks)
+    with O.variant("R"):                  # correctly rounded libm: nothing may differ
+        same1, same2 = recompute()
+    assert same1 == len(picks) and same2 == len(picks)
 
 
 def test_counter_seeded_image_converges_to_the_reference_seeded_one(ctx, oracle):
@@ -441,8 +483,9 @@ def test_fast_math_is_statistically_equivalent(ctx, name, mean_tol):
 def test_full_tables_fifty_shapes_fifty_materials(ctx, oracle):
     """The POD's limits (headers/GLOBALS.h:87-89): 50 shapes (25 boxes, most rotated, some flat,
     and 25 spheres: 425 of the 450 attributes), 50 materials of all four kinds, some blurred,
-    10 important shapes, depth 12.  Same bar as the scene files: >= 98 % of pixels within 1e-4
-    after two samples with the reference seeds."""
+    10 important shapes, depth 12.  Same bars as the scene files after two samples with the
+    reference seeds: >= 98 % of pixels within 1e-4 of variant F, every plane of every pixel
+    bit-identical to variant R."""
     import ptk
     O = oracle
     rng = np.random.default_rng(2024)
@@ -488,3 +531,7 @@ def test_full_tables_fifty_shapes_fifty_materials(ctx, oracle):
     assert ok.mean() >= 0.98
     # the oracle reports the last pass's bounce rays, the library the whole call's
     assert abs(grays - 2 * rays) <= 0.02 * 2 * rays
+    with O.variant("R"):
+        acc_r = O.new_accumulators(48, 32)
+        O.render(c, acc_r, 2, 0, PIN_SEED, threads=4)
+    assert _mismatch_report(planes, acc_r, 48) == ""
