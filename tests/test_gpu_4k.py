@@ -1,0 +1,158 @@
+"""GPU parity at 3840x2160: the sizes of the two eight-GPU jobs (cornell_crystal 4K
+accumulation; Box_Grid 4K + row-band denoiser).  8 294 400 pixels: 1.26 GB of planes,
+133 MB of reference seeds per pass, 8160 path-trace workgroups, 32 400 denoiser tiles.
+
+Whole frames cannot be recomputed on the CPU in test time, so each stage is checked on a
+random sample of its outputs recomputed by the CPU oracle from the same inputs, plus
+size-independent properties (row bands tile the whole-frame result; split calls equal one
+call).  Bars are those of the small frames: path trace bit-identical to the oracle's
+variant R on every checked pixel and >= 99 % to variant F; denoiser bandwidths, filtered
+colour and weight sum within 2e-5 relative.
+"""
+import numpy as np
+import pytest
+
+from conftest import PIN_SEED, scene_path, weights_path
+
+pytestmark = pytest.mark.gpu
+
+W, H = 3840, 2160
+P = W * H
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ptk
+    c = ptk.Context(0)
+    yield c
+    c.close()
+
+
+def _sample_vector(s):
+    return np.float32(list(s.xyz) + list(s.normal) + list(s.albedo1) + list(s.albedo2)
+                      + list(s.world_pos) + [s.direct_light])
+
+
+@pytest.mark.parametrize("name", ["cornell_crystal", "Box_Grid"])
+def test_one_reference_seeded_pass_spot_checked(ctx, oracle, name):
+    import ptk
+    O = oracle
+    consts = O.build_constants(O.load_scene(scene_path(name)), W, H, 4, 0.005, True)
+    ctx.set_math_mode(ptk.MATH_EXACT)
+    ctx.set_constants(consts)
+    rays, glo = ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    seeds, glo_cpu = O.seed_stream(PIN_SEED, P)
+    assert glo == glo_cpu
+    assert P <= rays <= 4 * P
+    got = ctx.read_planes(0, 16)
+    rng = np.random.default_rng(41)
+    picks = np.concatenate([rng.choice(P, 3990, replace=False),
+                            # the four corners, the last pixel of the first row, the first of the last
+                            [0, W - 1, P - W, P - 1, W, P - W - 1, P // 2, P // 2 + W // 2, 1, P - 2]])
+
+    def matching():
+        n = 0
+        for i in picks:
+            row, col = divmod(int(i), W)
+            s = O.render_sample(consts, row, col, int(seeds[i, 0]), int(seeds[i, 1]))
+            n += np.array_equal(got[:, i], _sample_vector(s), equal_nan=True)
+        return n
+
+    assert matching() >= 0.99 * len(picks)          # variant F: glibc's float libm
+    with O.variant("R"):
+        assert matching() == len(picks)             # correctly rounded libm: all of them
+    # after one sample every running deviation is the sample's deviation from itself
+    assert not ctx.read_planes(ptk.PL_SD, 6).any()
+
+
+def test_box_grid_denoise_bands_crops_and_exposure(ctx, oracle):
+    """Box_Grid, 16 spp with features, BEST.txt, N = 1: the eight row bands of an eight-GPU
+    split tile the whole-frame result bit for bit; twelve 48x48 crops (corners and edges
+    included) recomputed on the CPU from the read-back accumulators agree within the
+    small-frame tolerances; the exposure reduce agrees with the double sum to 1e-9 and
+    with the reference's sequential fp32 sum to the accuracy that sum has at this size."""
+    import ptk
+    import torch
+    import multigpu
+    O = oracle
+    consts = O.build_constants(O.load_scene(scene_path("Box_Grid")), W, H, 4, 0.005, True)
+    ctx.set_constants(consts)
+    ctx.set_stream_id(0)
+    ctx.render(7, ptk.SEED_COUNTER)
+    ctx.render(9, ptk.SEED_COUNTER)
+    assert ctx.sample_count == 16
+    w = O.load_weights(weights_path("BEST"))
+    full = ctx.denoise(w, 1, 0)
+    den, wc = multigpu.device_denoised(ctx, torch.device("cuda", 0))
+    den.zero_()
+    wc.zero_()
+    torch.cuda.synchronize()
+    for r in range(8):
+        y0, y1 = multigpu.row_band(H, 8, r)
+        ctx.denoise_rows(w, 1, 0, y0, y1)
+    assert np.array_equal(den.cpu().numpy().T, full["denoised"], equal_nan=True)
+    assert np.array_equal(wc.cpu().numpy(), full["wcSum"], equal_nan=True)
+
+    planes = ctx.read_planes()
+    img = planes.reshape(-1, H, W)
+    rng = np.random.default_rng(17)
+    C = 48
+    origins = [(0, 0), (W - C, 0), (0, H - C), (W - C, H - C), (W // 2, 0), (0, H // 2)]
+    origins += [(int(rng.integers(0, W - C)), int(rng.integers(0, H - C))) for _ in range(6)]
+    checked = 0
+    for x0, y0 in origins:
+        crop = np.ascontiguousarray(img[:, y0:y0 + C, x0:x0 + C]).reshape(-1, C * C)
+        _, var = O.forward_prop(crop, C, C, 16, w, threads=4)
+        d, wsum = O.filter(crop, var, C, C, 16, 1, threads=4)
+        # a crop clamps at its own edges: compare where the crop's edge is the image's edge
+        # or the 7x7 window stays inside the crop
+        ok = np.zeros((C, C), bool)
+        ok[3 if y0 > 0 else 0:C - 3 if y0 + C < H else C, 3 if x0 > 0 else 0:C - 3 if x0 + C < W else C] = True
+        sel = (slice(y0, y0 + C), slice(x0, x0 + C))
+        g_var = full["variances"].reshape(H, W, 7)[sel][ok]
+        g_den = full["denoised"].reshape(H, W, 3)[sel][ok]
+        g_wc = full["wcSum"].reshape(H, W)[sel][ok]
+        assert np.allclose(g_var, var.reshape(C, C, 7)[ok], rtol=2e-5, atol=1e-7)
+        assert np.allclose(g_den, d.reshape(C, C, 3)[ok], rtol=2e-5, atol=1e-7, equal_nan=True)
+        assert np.allclose(g_wc, wsum.reshape(C, C)[ok], rtol=2e-5, atol=1e-7)
+        checked += int(ok.sum())
+    assert checked > 20000
+
+    # Exposure.  The library sums the fp32 per-pixel terms in double; the reference adds the
+    # 8.3 M terms one after another in fp32 (Renderers.cpp:1151-1159).  Each of its additions
+    # rounds the running sum (up to 2.4e7 here, ulp 2) by at most half an ulp, so its result
+    # carries an error of order sqrt(n) * 2^-24 ~ 2e-4 relative (worst case n * 2^-24); 1e-3
+    # bounds both that and the distance between the two results.
+    e_gpu, raw_gpu = ctx.auto_exposure(ptk.EXPOSURE_CPU)
+    e_cpu, raw_cpu = O.auto_exposure(planes, W, H, 16, 0)
+    assert abs(raw_gpu - raw_cpu) <= 1e-9 * raw_cpu
+    exact = np.float32(raw_cpu) * (np.float32(9.6) / np.float32(W) * np.float32(H) * np.float32(16))
+    assert abs(e_gpu - exact) <= 2e-7 * exact           # the double sum, rounded once, scaled as written
+    assert abs(e_cpu - exact) <= 1e-3 * exact           # the reference's own accumulation error
+    assert abs(e_gpu - e_cpu) <= 1e-3 * e_cpu
+    e_mean, _ = ctx.auto_exposure(ptk.EXPOSURE_MEAN)
+    assert abs(e_mean - 9.6 * raw_cpu / (P * 16.0)) <= 1e-6 * e_mean
+
+
+def test_counter_seeded_4k_split_calls_and_streams(ctx, oracle):
+    """cornell_crystal 4K, device seeds: 5 spp in one call equal 2 + 3 in two; another stream
+    id gives another image with the same mean (two independent 41 M-sample estimates)."""
+    import ptk
+    O = oracle
+    ctx.set_constants(O.build_constants(O.load_scene(scene_path("cornell_crystal")), W, H, 4, 0.005,
+                                        False))
+    ctx.set_stream_id(3)
+    ctx.render(5, ptk.SEED_COUNTER)
+    a = ctx.read_planes(0, 3)
+    ctx.reset()
+    ctx.render(2, ptk.SEED_COUNTER)
+    ctx.render(3, ptk.SEED_COUNTER)
+    assert np.array_equal(a, ctx.read_planes(0, 3), equal_nan=True)
+    ctx.reset()
+    ctx.set_stream_id(4)
+    ctx.render(5, ptk.SEED_COUNTER)
+    b = ctx.read_planes(0, 3)
+    ctx.set_stream_id(0)
+    assert not np.array_equal(a, b)
+    ma, mb = np.nanmean(a.astype(np.float64)), np.nanmean(b.astype(np.float64))
+    assert abs(ma / mb - 1.0) < 3e-3

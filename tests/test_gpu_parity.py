@@ -316,31 +316,81 @@ def test_full_size_frame_spot_checked_against_the_cpu(ctx, oracle, name):
     assert same1 == len(picks) and same2 == len(picks)
 
 
-def test_counter_seeded_image_converges_to_the_reference_seeded_one(ctx, oracle):
-    """RMSE bound: 64 spp with device seeds against 64 spp with the reference's seed
-    stream, both on the GPU, and the latter against the oracle's mean."""
+@pytest.mark.parametrize("name,mse_tol", [("cornell_crystal", 0.05), ("MultiLightGlass", 0.05),
+                                          ("Box_Grid", 0.10)])
+def test_counter_seeds_are_statistically_equivalent_to_reference_seeds(ctx, name, mse_tol):
+    """The device's counter-based seeds (the benchmarked mode) against the reference's
+    sequential seed stream, both in exact math: 256 samples of each, measured against one
+    4096-spp render on a third stream.  The two 256-spp images must be equally good estimates:
+    relative MSE within 5 % of each other (10 % on Box_Grid, whose error is dominated by few
+    bright pixels), image means within 0.2 % of the 4096-spp mean."""
+    import ptk
+    W, H = 240, 135
+    raw, _, _ = ptk.scene_constants(scene_path(name), W, H, 4, 0.005, False)
+    ctx.set_math_mode(ptk.MATH_EXACT)
+    ctx.set_constants(raw)
+    ctx.set_stream_id(1234)
+    ctx.render(4096, ptk.SEED_COUNTER)
+    ref = ctx.read_planes(0, 3).astype(np.float64) / 4096.0
+    ctx.set_stream_id(0)
+
+    def quality(img):
+        return np.nanmean(img), np.nanmean((img - ref) ** 2 / (ref ** 2 + 1e-3))
+
+    ctx.reset()
+    ctx.render(256, ptk.SEED_COUNTER)
+    m_ctr, mse_ctr = quality(ctx.read_planes(0, 3).astype(np.float64) / 256.0)
+    ctx.reset()
+    ctx.render(256, ptk.SEED_REFERENCE, PIN_SEED)
+    m_ref, mse_ref = quality(ctx.read_planes(0, 3).astype(np.float64) / 256.0)
+    m = np.nanmean(ref)
+    assert abs(m_ctr / m - 1.0) < 2e-3
+    assert abs(m_ref / m - 1.0) < 2e-3
+    assert abs(mse_ctr / mse_ref - 1.0) < mse_tol
+
+
+def test_counter_seeds_are_uncorrelated_across_pixels_and_samples(ctx, oracle):
+    """Independence of the per-(pixel, sample, stream) seeds, observed through the kernel:
+    with no shapes every path is the camera ray into the sky, whose blue channel is a smooth
+    monotone function of the second jitter draw.  Residuals about each pixel's own mean must
+    be uncorrelated between neighbouring pixels (same sample), between consecutive samples
+    (same pixel) and between streams, within three standard errors of zero."""
     import ptk
     O = oracle
-    W, H = 160, 90
-    sc = O.load_scene(scene_path("cornell_crystal"))
-    consts = O.build_constants(sc, W, H, 4, 0.005, False)
-    acc = O.new_accumulators(W, H)
-    O.render(consts, acc, 64, 0, PIN_SEED, threads=8)
-    ctx.set_constants(consts)
-    ctx.render(64, ptk.SEED_REFERENCE, PIN_SEED)
-    ref_seeded = ctx.read_planes(0, 3) / 64
-    ctx.reset()
-    ctx.render(64, ptk.SEED_COUNTER)
-    ctr_seeded = ctx.read_planes(0, 3) / 64
-    orc = acc[0:3] / 64
-    # same seeds: means agree to 1e-4; different seeds: within Monte Carlo noise
-    assert abs(np.nanmean(ref_seeded) / np.nanmean(orc) - 1.0) < 1e-4
-    assert abs(np.nanmean(ctr_seeded) / np.nanmean(orc) - 1.0) < 2e-2
-    noise = np.sqrt(np.nanmean((ref_seeded - orc) ** 2))
-    rmse = np.sqrt(np.nanmean((ctr_seeded - orc) ** 2))
-    spread = np.sqrt(np.nanmean(orc ** 2))
-    assert noise < 0.02 * spread      # matched seeds: only a few diverged paths
-    assert rmse < 1.0 * spread        # independent seeds at 64 spp: bounded by the estimator noise
+    W, H, S = 160, 90, 48
+    consts = O.build_constants(O.load_scene(scene_path("cornell")), W, H, 1, 0.5, False)
+    consts.num_shapes = 0
+    consts.num_imp = 0
+
+    def residuals(stream):
+        ctx.set_constants(consts)
+        ctx.set_stream_id(stream)
+        v = np.empty((S, H, W), np.float64)
+        prev = np.zeros(W * H, np.float64)
+        for k in range(S):
+            ctx.render(1, ptk.SEED_COUNTER)
+            acc = ctx.read_planes(2, 1)[0].astype(np.float64)
+            v[k] = (acc - prev).reshape(H, W)
+            prev = acc
+        return v - v.mean(axis=0, keepdims=True)
+
+    r = residuals(0)
+    assert r.std() > 0.01                       # the jitter does move the ray
+
+    def corr(a, b):
+        return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+
+    # removing each pixel's mean over S samples leaves a correlation of -1/(S-1) between
+    # samples of one pixel; it does not touch the correlation between different pixels
+    checks = {
+        "next pixel in the row": (corr(r[:, :, :-1], r[:, :, 1:]), 0.0, S * H * (W - 1)),
+        "next pixel in the column": (corr(r[:, :-1, :], r[:, 1:, :]), 0.0, S * (H - 1) * W),
+        "next sample": (corr(r[:-1], r[1:]), -1.0 / (S - 1), (S - 1) * H * W),
+        "next stream": (corr(r, residuals(1)), 0.0, S * H * W),
+    }
+    ctx.set_stream_id(0)
+    for what, (c, expect, n) in checks.items():
+        assert abs(c - expect) < 3.0 / np.sqrt(n), (what, c, expect, n)
 
 
 def test_denoise_row_bands_tile_the_full_result(ctx, oracle):
