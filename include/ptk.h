@@ -243,6 +243,25 @@ int ptk_refresh_std_dev(ptk_ctx* ctx);
  * unscaled sum of per-pixel luminance in double. */
 int ptk_auto_exposure(ptk_ctx* ctx, int formula, float* exposure, double* raw_sum);
 
+/* The exposure reduce for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same kernels and arithmetic as
+ * ptk_auto_exposure, but context-free: the input is the device address of three
+ * colour planes (plane-major, `pixels` floats each, width * height == pixels; e.g.
+ * plane 0 of ptk_planes_device), the outputs are DEVICE pointers (either may be
+ * null, not both) written by the last kernel, everything is enqueued on
+ * `hip_stream` (a hipStream_t; null = the default stream) of the CURRENT device
+ * and nothing is synchronised.  The partial sums live in a 4 KiB array inside the
+ * library's code object, one copy per GPU, held until the process ends; the call
+ * performs no hipMalloc / hipFree and no host<->device copy.  pixels above
+ * PTK_STATIC_MAX_PIXELS is PTK_ERR_ARG.  All calls on one GPU share that array:
+ * calls that overlap on one GPU (other streams or threads) race; issue them on
+ * one stream. */
+#define PTK_STATIC_MAX_PIXELS ((size_t)1 << 28)
+int ptk_auto_exposure_static(const float* colour_planes_d, size_t pixels, int width, int height,
+                             int sample_count, int formula, float* exposure_d, double* raw_sum_d,
+                             void* hip_stream);
+
 /* Replaces CUDADenoiserNN::ForwardProp (CUDADenoiserNN.cu:297-368) followed by
  * CUDADenoiser::denoise (CUDADenoiser.cu:123-182), with the arithmetic of the
  * sequential copies (DenoiserNN.cpp:12-301, Denoiser.cpp:222-355): 36

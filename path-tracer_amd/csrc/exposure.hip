@@ -10,6 +10,8 @@
 // sums in double; the wave reduces with DPP row operations.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "ptk_dev.h"
 
 #pragma clang fp contract(off)
@@ -114,6 +116,82 @@ hipError_t ptk_launch_exposure(const float* planes, size_t pixels, int formula, 
     else
         hipLaunchKernelGGL(exposure_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, planes,
                            pixels, sum_d);
+    return hipGetLastError();
+}
+
+// ---- the exposure reduce for callers that cannot allocate.
+//
+// The shard sums live in a file-scope device array instead of a hipMalloc'd
+// buffer, and the result is finished on the device (a one-thread kernel adds the
+// shards in index order and applies the formula exactly as the host code of
+// ptk_auto_exposure does) and stored through device pointers, so the call
+// enqueues a memset and two kernels and nothing else.  Every GPU holds its own
+// copy of the array at its own address; the address is looked up once per
+// device, with that device current, and kept.  All calls on one GPU share the
+// array: it is cleared at the start of each call, and calls that overlap on one
+// GPU (different streams, or different threads) race on it.
+namespace {
+
+static __device__ __align__(256) double scratch[PTK_EXPOSURE_SUM_DOUBLES];   // 4 KiB per GPU
+
+constexpr int MAX_DEVICES = 64;
+double* g_scratch_ptr[MAX_DEVICES];     // device address of `scratch` on each GPU, once known
+std::mutex g_scratch_mutex;
+
+__global__ void exposure_finish_kernel(const double* __restrict__ shards, int formula, int width,
+                                       int height, unsigned long long pixels, int sample_count,
+                                       float* __restrict__ exposure, double* __restrict__ raw_sum)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double sum = 0.0;
+    for (int i = 0; i < PTK_EXPOSURE_SHARDS; i++) sum += shards[i * PTK_EXPOSURE_SHARD_STRIDE];
+    if (raw_sum) *raw_sum = sum;
+    if (exposure) {
+        const float n = (float)sample_count;
+        float e = (float)sum;
+        if (formula == PTK_EXPOSURE_CPU)
+            e *= 9.6f / (float)width * (float)height * n;   // as written, left to right
+        else if (formula == PTK_EXPOSURE_SKEPU)
+            e = 9.6f * e / (float)(int)pixels * n;
+        else
+            e = (float)(9.6 * sum / ((double)pixels * (double)sample_count));
+        *exposure = e;
+    }
+}
+
+}  // namespace
+
+hipError_t ptk_exposure_static_setup(double** ptr_out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        double* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[dev] = p;
+    }
+    if (ptr_out) *ptr_out = g_scratch_ptr[dev];
+    return hipSuccess;
+}
+
+hipError_t ptk_launch_exposure_static(const float* planes, size_t pixels, int width, int height,
+                                      int sample_count, int formula, float* exposure_d,
+                                      double* raw_sum_d, hipStream_t stream)
+{
+    double* shards = nullptr;
+    hipError_t e = ptk_exposure_static_setup(&shards);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(shards, 0, PTK_EXPOSURE_SUM_DOUBLES * sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    e = ptk_launch_exposure(planes, pixels, formula == PTK_EXPOSURE_SKEPU ? 1 : 0, shards, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(exposure_finish_kernel, dim3(1), dim3(64), 0, stream, shards, formula, width,
+                       height, (unsigned long long)pixels, sample_count, exposure_d, raw_sum_d);
     return hipGetLastError();
 }
 

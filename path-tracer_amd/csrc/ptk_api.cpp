@@ -358,6 +358,8 @@ int ptk_create(int device, ptk_ctx** out)
     if (e == hipSuccess) e = hipMalloc((void**)&c->rays_d, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&c->sum_d, PTK_EXPOSURE_SUM_DOUBLES * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&c->weights_d, 530 * sizeof(float));
+    // this GPU's address of the array behind ptk_auto_exposure_static, while set-up may allocate
+    if (e == hipSuccess) e = ptk_exposure_static_setup(nullptr);
     if (e != hipSuccess) {
         ptk_destroy(c);
         return fail(PTK_ERR_HIP, "ptk_create: %s", hipGetErrorString(e));
@@ -1022,6 +1024,8 @@ int ptk_auto_exposure(ptk_ctx* c, int formula, float* exposure, double* raw_sum)
     if (!c) return fail(PTK_ERR_ARG, "ptk_auto_exposure: null context");
     if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_auto_exposure before ptk_set_constants");
     if (formula < 0 || formula > 2) return fail(PTK_ERR_ARG, "ptk_auto_exposure: formula %d", formula);
+    if (exposure && c->sample_count < 1)
+        return fail(PTK_ERR_STATE, "ptk_auto_exposure: no samples accumulated");
     int rc = bind(c);
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->sum_d, 0, PTK_EXPOSURE_SUM_DOUBLES * sizeof(double), c->stream));
@@ -1046,6 +1050,28 @@ int ptk_auto_exposure(ptk_ctx* c, int formula, float* exposure, double* raw_sum)
             e = (float)(9.6 * sum / ((double)c->pixels * (double)c->sample_count));
         *exposure = e;
     }
+    return PTK_OK;
+}
+
+int ptk_auto_exposure_static(const float* colour_planes_d, size_t pixels, int width, int height,
+                             int sample_count, int formula, float* exposure_d, double* raw_sum_d,
+                             void* hip_stream)
+{
+    if (!colour_planes_d) return fail(PTK_ERR_ARG, "ptk_auto_exposure_static: null planes");
+    if (!exposure_d && !raw_sum_d)
+        return fail(PTK_ERR_ARG, "ptk_auto_exposure_static: no output pointer");
+    if (formula < 0 || formula > 2)
+        return fail(PTK_ERR_ARG, "ptk_auto_exposure_static: formula %d", formula);
+    if (pixels < 1 || pixels > PTK_STATIC_MAX_PIXELS)
+        return fail(PTK_ERR_ARG, "ptk_auto_exposure_static: %zu pixels outside [1, %zu]", pixels,
+                    (size_t)PTK_STATIC_MAX_PIXELS);
+    if (width < 1 || height < 1 || (size_t)width * (size_t)height != pixels)
+        return fail(PTK_ERR_ARG, "ptk_auto_exposure_static: %dx%d is not %zu pixels", width, height,
+                    pixels);
+    if (exposure_d && sample_count < 1)
+        return fail(PTK_ERR_ARG, "ptk_auto_exposure_static: sample_count %d < 1", sample_count);
+    HIP_TRY(ptk_launch_exposure_static(colour_planes_d, pixels, width, height, sample_count, formula,
+                                       exposure_d, raw_sum_d, (hipStream_t)hip_stream));
     return PTK_OK;
 }
 

@@ -135,6 +135,16 @@ hipError_t ptk_launch_render_bvh_fast(const RenderArgs& a, int max_depth, bool f
 hipError_t ptk_launch_exposure(const float* planes, size_t pixels, int formula, double* sum_d,
                                hipStream_t stream);
 
+// The same reduce with the shard sums in a file-scope device array and the result
+// finished on the device (exposure_d / raw_sum_d: device memory, either may be
+// null): enqueues a memset and two kernels, allocates nothing.
+// ptk_exposure_static_setup looks up that array's address on the current device
+// (once per device) and is also called by the launcher.
+hipError_t ptk_exposure_static_setup(double** ptr_out);
+hipError_t ptk_launch_exposure_static(const float* planes, size_t pixels, int width, int height,
+                                      int sample_count, int formula, float* exposure_d,
+                                      double* raw_sum_d, hipStream_t stream);
+
 // stdDev[k] = (sdv[3k] + sdv[3k+1] + sdv[3k+2]) / n for k < 5, sdv[15] / n for k = 5.
 hipError_t ptk_launch_refresh_std_dev(float* planes, size_t pixels, int sample_count,
                                       hipStream_t stream);

@@ -26,7 +26,7 @@ EXPORTS = [
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
     "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_save_target",
     "ptk_set_target", "ptk_train_step", "ptk_timing", "ptk_synchronize", "ptk_set_scene",
-    "ptk_check_scene", "ptk_set_camera",
+    "ptk_check_scene", "ptk_set_camera", "ptk_auto_exposure_static",
 ]
 SCENE_VISIT_ALL = 1
 SCENE_ATTRS = 13
@@ -160,6 +160,8 @@ def load():
     L.ptk_set_scene.argtypes = [vp, C.POINTER(SceneDesc), C.c_int, C.POINTER(SceneStats)]
     L.ptk_set_camera.argtypes = [vp, fp, fp, fp, fp]
     L.ptk_check_scene.argtypes = [C.POINTER(SceneDesc), C.POINTER(SceneStats)]
+    L.ptk_auto_exposure_static.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                           vp, vp]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
     for name in EXPORTS:
