@@ -167,6 +167,8 @@ def _bind(L):
         L.orc_filter_variant.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp,
                                          C.c_int]
         L.orc_filter_variant.restype = None
+        L.orc_mad_procedure.argtypes = [fp, C.c_size_t, fp]
+        L.orc_mad_procedure.restype = None
         L.orc_load_weights.argtypes = [C.c_char_p, fp, fp, fp]
         L.orc_load_weights.restype = C.c_int
         L.orc_tonemap8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -314,6 +316,14 @@ def load_weights(path):
     if rc != 0:
         raise IOError("cannot load weights %s (rc=%d)" % (path, rc))
     return w12, w23, w34
+
+
+def mad_procedure(windows):
+    """The "median getter" procedure on each row of an (n, 9) array."""
+    w = np.ascontiguousarray(windows, dtype=np.float32).reshape(-1, 9)
+    out = np.empty(len(w), np.float32)
+    lib().orc_mad_procedure(_fp(w), len(w), _fp(out))
+    return out
 
 
 def forward_prop(acc, width, height, sample_count, weights, threads=1):

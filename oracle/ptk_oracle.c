@@ -958,6 +958,17 @@ static float mad_procedure(float* v)
     return m[0];
 }
 
+/* The procedure alone, for tests of other implementations of it: out[i] = its
+ * result for the nine values v[9 i .. 9 i + 8]. */
+void orc_mad_procedure(const float* v, size_t n, float* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float w[9];
+        memcpy(w, v + 9 * i, sizeof w);
+        out[i] = mad_procedure(w);
+    }
+}
+
 static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 static inline float softplusf(float x) { return logf(1.0f + expf(x)); }
 

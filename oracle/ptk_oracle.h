@@ -160,6 +160,10 @@ void orc_filter_variant(const float* acc, const float* variances7, int width, in
 
 int orc_load_weights(const char* path, float* w12, float* w23, float* w34);
 
+/* The "median getter" procedure of DenoiserNN.cpp:190-256 alone, as written:
+ * out[i] = its result for the nine values v[9 i .. 9 i + 8]. */
+void orc_mad_procedure(const float* v, size_t n, float* out);
+
 /* CUDAPostProcess for display metrics 0..6 (CUDARender.cu:959-1066): post is
  * interleaved rgb, P * 3 floats.  Returns -1 for an unsupported metric. */
 int orc_post_process(const float* planes, const float* denoised_interleaved, int width, int height,

@@ -21,6 +21,10 @@ namespace {
 #ifndef PTK_DN_WAVES
 #define PTK_DN_WAVES 3
 #endif
+// measurement builds: bit 0 drops the "median getter", bit 1 the 7x7 statistics
+#ifndef PTK_DN_ABLATE
+#define PTK_DN_ABLATE 0
+#endif
 #ifndef PTK_DN_WAVES_FILTER
 #define PTK_DN_WAVES_FILTER 3
 #endif
@@ -32,6 +36,10 @@ constexpr int FH = 3;                  // feature halo (7x7 window)
 constexpr int FW = TW + 2 * FH;        // 38
 constexpr int FR = TH + 2 * FH;        // 14
 constexpr int FPLANE = FW * FR;        // 532 words per feature plane
+constexpr int PTILE_FLOATS = 10 * FPLANE;   // primaries and primaries / 49
+#ifndef PTK_DN_LDS_PAD
+#define PTK_DN_LDS_PAD 0               // measurement builds: unused LDS words, to lower occupancy
+#endif
 
 DEV int clampi(int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); }
 
@@ -96,8 +104,38 @@ DEV void mg_insert_pass2(float v, Slots& s)
     s.m3 = (c1 || c2) ? m3 : (c3 ? v : fill);
     s.m4 = c4 ? v : s.m4;
 }
+// The same procedure as a network in which every select is one v_cndmask on a wave mask
+// held in scalar registers (mad_network.h).  Written with explicit instructions because the
+// compiler turns the select form above into a branch per insertion (all four upper slots
+// share one condition), which costs more than the selects and keeps the five channels'
+// chains from being interleaved.
+#define PTK_MAD_FN __device__ __forceinline__
+#define PTK_MAD_UNROLL _Pragma("unroll")
+#include "mad_network.h"
+struct WaveOps {
+    using Mask = unsigned long long;
+    static DEV Mask gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2 /* ordered > */); }
+    static DEV Mask land(Mask a, Mask b) { return a & b; }
+    static DEV Mask lor(Mask a, Mask b) { return a | b; }
+    static DEV Mask andn(Mask a, Mask b) { return a & ~b; }
+    static DEV Mask lnot(Mask a) { return ~a; }
+    static DEV float sel(Mask c, float x, float y)
+    {
+        float r;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(y), "v"(x), "s"(c));
+        return r;
+    }
+    static DEV float fabs(float x) { return __builtin_fabsf(x); }
+};
+#ifndef PTK_DN_MAD_NETWORK
+#define PTK_DN_MAD_NETWORK 1
+#endif
+
 DEV float mad_procedure(float (&v)[9])
 {
+#if PTK_DN_MAD_NETWORK
+    return ptk_mad::Network<WaveOps>::run(v);
+#endif
     Slots s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < 9; i++) mg_insert_pass1(v[i], s);
@@ -142,8 +180,10 @@ DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 //   [460, 530) third layer  w34[10*node + input]
 //
 // 36 features + MLP for the pixel at tile coordinates (ly, lx) of an LDS tile
-// `t` of 15 planes [FR][FW]: the primaries q, then q/49, then q/9 (the terms
-// the reference adds up for its 7x7 and 3x3 means, each rounded once).
+// `t` of 10 planes [FR][FW]: the primaries q, then q/49 (the terms the reference
+// adds up for its 7x7 mean, each rounded once; that mean is reproduced bit for bit.
+// The 3x3 mean only feeds the mean absolute deviation, which is compared within a
+// tolerance, and is formed as sum / 9).
 //
 // The five feature channels are processed one after another in a rolled loop
 // and each channel's seven features are folded into the ten first-layer sums
@@ -164,19 +204,21 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
     for (int k = 0; k < 5; k++) {
         const float* tk = t + k * FPLANE + ly * FW + lx;   // window origin (top-left of 7x7)
         const float* tk49 = tk + 5 * FPLANE;
-        const float* tk9 = tk + 10 * FPLANE;
         float fk[7];
         fk[0] = tk[FH * FW + FH];
         fk[1] = k == 0 ? sd5[0] : k == 1 ? sd5[1] : k == 2 ? sd5[2] : k == 3 ? sd5[3] : sd5[4];
 
         // 7x7 mean: the reference adds q/49 term by term in row-major order
         float mean7 = 0.0f;
+        float ss = 0.0f;
+#if PTK_DN_ABLATE & 2
+        mean7 = tk49[0]; ss = tk[0];             // measurement build: no 7x7 statistics
+#else
 #pragma unroll
         for (int j = 0; j < 7; j++)
 #pragma unroll
             for (int i = 0; i < 7; i++) mean7 += tk49[j * FW + i];
         // 7x7 standard deviation about that mean
-        float ss = 0.0f;
 #pragma unroll
         for (int j = 0; j < 7; j++)
 #pragma unroll
@@ -184,6 +226,7 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
                 float d = tk[j * FW + i] - mean7;
                 ss = __builtin_fmaf(d, d, ss);
             }
+#endif
         fk[2] = mean7;
         fk[3] = __builtin_sqrtf(ss * (1.0f / 49.0f));
 
@@ -195,8 +238,9 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
             for (int i = 0; i < 3; i++) {
                 const int o = (FH - 1 + j) * FW + FH - 1 + i;
                 win[j * 3 + i] = tk[o];
-                mean3 += tk9[o];
+                mean3 += tk[o];
             }
+        mean3 *= 1.0f / 9.0f;
         {
 #pragma clang fp contract(off)
             // Sobel sums in the reference's accumulation order; zero taps add +-0
@@ -239,7 +283,11 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
             for (int j = 0; j < 3; j++)
 #pragma unroll
                 for (int i = 0; i < 3; i++) win[j * 3 + i] = tk[(FH - 1 + j) * FW + FH - 1 + i];
+#if PTK_DN_ABLATE & 1
+            mad[k] = win[4] + win[0] * win[8];   // measurement build: no "median getter"
+#else
             mad[k] = mad_procedure(win);
+#endif
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -271,7 +319,7 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
     }
 }
 
-// Loads the (32+6)x(8+6) tile of primaries (and their /49, /9 images) around
+// Loads the (32+6)x(8+6) tile of primaries (and their /49 images) around
 // the block's outputs.  All of a thread's global loads are issued before the
 // first quotient is formed, so the tile costs one memory latency, not three.
 DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int x0, int y0,
@@ -279,7 +327,7 @@ DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, in
 {
     constexpr int EPT = (FPLANE + 255) / 256;
     const Recip three_n = make_recip(3.0f * n), one_n = make_recip(n);
-    const Recip r49 = make_recip(49.0f), r9 = make_recip(9.0f);
+    const Recip r49 = make_recip(49.0f);
     float raw[EPT][13];
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
@@ -311,7 +359,6 @@ DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, in
             for (int k = 0; k < 5; k++) {
                 t[k * FPLANE + e] = q[k];
                 t[(5 + k) * FPLANE + e] = div_by(q[k], r49);
-                t[(10 + k) * FPLANE + e] = div_by(q[k], r9);
             }
         }
     }
@@ -346,7 +393,7 @@ DEV bool tile_origin(const DenoiseArgs& a, int& x0, int& y0)
 
 __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(DenoiseArgs a)
 {
-    __shared__ float tile[15 * FPLANE];
+    __shared__ float tile[PTILE_FLOATS + PTK_DN_LDS_PAD];
     const int W = a.width, H = a.height;
     const size_t P = (size_t)W * H;
     const float n = (float)a.sample_count;
@@ -628,7 +675,7 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES_FUSED) void denoise_fused_kernel(
     const size_t P = (size_t)W * H;
     const int SW = TW + 2 * N, SS = SW * (TH + 2 * N);
     float* ptile = smem;
-    float* ftile = smem + 15 * FPLANE;
+    float* ftile = smem + PTILE_FLOATS;
     const float n = (float)a.sample_count;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     int x0, y0;
@@ -750,7 +797,7 @@ hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
 
 hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream)
 {
-    size_t lds = filter_lds_bytes(a.n) + 15 * FPLANE * sizeof(float);
+    size_t lds = filter_lds_bytes(a.n) + PTILE_FLOATS * sizeof(float);
     if (a.n == 1) return launch_dyn(denoise_fused_kernel<1>, a, lds, stream);
     return launch_dyn(denoise_fused_kernel<0>, a, lds, stream);
 }

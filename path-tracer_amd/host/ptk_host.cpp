@@ -709,3 +709,31 @@ extern "C" int ptkhost_resave_weights(const char* in_path, const char* out_path)
     st.denoiserNN.OutputWeights(out_path);
     return 0;
 }
+
+// ---- the denoiser's "median getter" network (csrc/mad_network.h), instantiated for the host
+// so that it can be checked against the literal loop without a GPU: out[i] = the network's
+// result for the nine values v[9 * i .. 9 * i + 8].
+#define PTK_MAD_FN inline
+#define PTK_MAD_UNROLL
+#include "../csrc/mad_network.h"
+namespace {
+struct HostOps {
+    using Mask = bool;
+    static bool gt(float a, float b) { return a > b; }
+    static bool land(bool a, bool b) { return a && b; }
+    static bool lor(bool a, bool b) { return a || b; }
+    static bool andn(bool a, bool b) { return a && !b; }
+    static bool lnot(bool a) { return !a; }
+    static float sel(bool c, float x, float y) { return c ? x : y; }
+    static float fabs(float x) { return std::fabs(x); }
+};
+}  // namespace
+
+extern "C" void ptkhost_mad_network(const float* v, size_t n, float* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float w[9];
+        for (int k = 0; k < 9; k++) w[k] = v[9 * i + k];
+        out[i] = ptk_mad::Network<HostOps>::run(w);
+    }
+}

@@ -456,6 +456,18 @@ def load_weights(path):
     return w12, w23, w34
 
 
+def mad_network_host(windows):
+    """The denoiser kernel's "median getter" network (csrc/mad_network.h) evaluated on the host
+    for each row of an (n, 9) array: the kernel's own code, instantiated with bools."""
+    H = _load_host()
+    H.ptkhost_mad_network.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float)]
+    H.ptkhost_mad_network.restype = None
+    w = np.ascontiguousarray(windows, dtype=np.float32).reshape(-1, 9)
+    out = np.empty(len(w), np.float32)
+    H.ptkhost_mad_network(_fp(w), len(w), _fp(out))
+    return out
+
+
 def resave_scene(in_path, out_path):
     """Scene::LoadScene then Scene::SaveScene."""
     if _load_host().ptkhost_resave_scene(os.fsencode(in_path), os.fsencode(out_path)) != 0:

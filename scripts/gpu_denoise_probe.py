@@ -23,10 +23,14 @@ def synthetic(W, H, spp=128, seed=1234):
 def main():
     W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    real = len(sys.argv) > 4 and sys.argv[4] == "real"     # a rendered frame instead of noise
     ctx = ptk.Context(0)
     raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", "MultiLightGlass.scene"), W, H, 4, 0.005, True)
     ctx.set_constants(raw)
-    ctx.write_planes(synthetic(W, H), 128)
+    if real:
+        ctx.render(128, ptk.SEED_COUNTER)
+    else:
+        ctx.write_planes(synthetic(W, H), 128)
     w = ptk.load_weights(os.path.join(ROOT, "data", "weights", "BEST.txt"))
     for N in (1, 3):
         for variant in (0, 1):

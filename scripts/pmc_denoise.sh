@@ -4,11 +4,12 @@ set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-pmc_dn}
+KIND=${2:-synthetic}
 mkdir -p "$OUT"
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-    --output-format csv -d "$OUT/a" -- python3 scripts/gpu_denoise_probe.py 1920 1080 4 > "$OUT/a.log"
+    --output-format csv -d "$OUT/a" -- python3 scripts/gpu_denoise_probe.py 1920 1080 4 $KIND > "$OUT/a.log"
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES \
-    --output-format csv -d "$OUT/b" -- python3 scripts/gpu_denoise_probe.py 1920 1080 4 > "$OUT/b.log"
+    --output-format csv -d "$OUT/b" -- python3 scripts/gpu_denoise_probe.py 1920 1080 4 $KIND > "$OUT/b.log"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 for sub in ("a", "b"):
