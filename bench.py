@@ -6,8 +6,13 @@ cornell_crystal at 1920x1080 (BASELINE.json configs[1]: 2000 spp, render only;
 the default 10 steps x 200 spp are exactly that job).  The accumulators live in
 HBM for the whole run and seeds are generated on the device, so nothing crosses
 PCIe inside the timed region.  With N > 1 ranks every rank renders the same
-number of samples of every pixel on its own seed stream (weak scaling) and each
-step ends with the per-frame accumulation all-reduce over RCCL.
+number of samples of every pixel on its own seed stream (weak scaling: the
+samples of the frame are split across the GPUs) and the frame ends, inside the
+timed region, with ONE accumulation exchange: the all-reduce of the colour planes
+over RCCL.  After the timed region the multi-rank run also times the two
+eight-GPU jobs of BASELINE.json at 3840x2160 (objects "config4" and "config5" of
+the result line): the sample-split render with its all-reduce, and the feature
+render + band-wise merge + row-band denoiser + gather.
 
 Prints one JSON line on rank 0.
 """
@@ -119,21 +124,18 @@ def denoise_probe(ctx, W, H, depth):
     render_ms = ctx.timing().render_ms
     out = {"workload": "MultiLightGlass %dx%d 128 spp + denoise N=1 BEST.txt" % (W, H),
            "render_msamples_per_s": W * H * 128 / render_ms / 1e3}
-    for variant, name in ((0, "two_pass"), (1, "fused")):
-        ts = []
-        for _ in range(12):
-            ctx.denoise(w, 1, variant, want_outputs=False)
-            t = ctx.timing()
-            ts.append((t.denoise_ms, t.features_ms, t.filter_ms))
-        ts = ts[2:]
-        avg = [sum(x[i] for x in ts) / len(ts) for i in range(3)]
-        out[name + "_ms"] = avg[0]
-        if variant == 0:
-            out["features_ms"], out["filter_ms"] = avg[1], avg[2]
-            out["features_gbs"] = W * H * 100 / avg[1] / 1e6
-            out["filter_gbs"] = W * H * 132 / avg[2] / 1e6
-        else:
-            out["fused_gbs"] = W * H * 104 / avg[0] / 1e6
+    ts = []
+    for _ in range(12):
+        ctx.denoise(w, 1, 0, want_outputs=False)
+        t = ctx.timing()
+        ts.append((t.denoise_ms, t.features_ms, t.filter_ms))
+    ts = ts[2:]
+    avg = [sum(x[i] for x in ts) / len(ts) for i in range(3)]
+    out["two_pass_ms"] = avg[0]
+    out["features_ms"], out["filter_ms"] = avg[1], avg[2]
+    # algorithmic bytes per pixel: features 72 read + 28 written, filter 116 read + 16 written
+    out["features_gbs"] = W * H * 100 / avg[1] / 1e6
+    out["filter_gbs"] = W * H * 132 / avg[2] / 1e6
     es = []
     for _ in range(12):
         ctx.auto_exposure(ptk.EXPOSURE_CPU)
@@ -168,6 +170,11 @@ def denoise_probe(ctx, W, H, depth):
     ev1.record()
     torch.cuda.synchronize()
     out["device_copy_gbs"] = 5 * 2 * n * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    # roofline fractions of the two stencils: against the 8 TB/s HBM peak and against what a
+    # plain copy reaches on this board
+    for k in ("features", "filter", "exposure", "post_process"):
+        out[k + "_frac"] = out[k + "_gbs"] / PEAK_HBM_GBS
+        out[k + "_frac_of_copy"] = out[k + "_gbs"] / out["device_copy_gbs"]
     return out
 
 
@@ -187,6 +194,95 @@ def hierarchy_probe(ctx, W, H):
             "device_mb": st["device_bytes"] / 1e6}
 
 
+def _barrier(args, gpu):
+    torch.cuda.synchronize()
+    dist.barrier(device_ids=[gpu]) if args.backend == "nccl" else dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(seconds, device):
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    multigpu.all_reduce_(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def config4_leg(ctx, args, rank, world, gpu, device):
+    """BASELINE.json configs[3]: cornell_crystal 3840x2160, the frame's samples split across
+    the ranks (625 per GPU: 5000 spp on eight), one all-reduce of the colour planes."""
+    W, H = args.leg_width, args.leg_height
+    per_gpu = 625
+    total = per_gpu * world
+    raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", "cornell_crystal.scene"),
+                                    W, H, args.depth, 0.005, False)
+    ctx.set_constants(raw)
+    ctx.set_stream_id(rank)
+    planes = multigpu.device_planes(ctx, device)
+    n_local = multigpu.shard_spp(total, world, rank)
+    ctx.render(8, ptk.SEED_COUNTER)
+    multigpu.all_reduce_(planes[0:3])
+    ctx.reset()
+    ctx.synchronize()
+    _barrier(args, gpu)
+    t0 = time.perf_counter()
+    ctx.render(n_local, ptk.SEED_COUNTER)
+    t1 = time.perf_counter()
+    multigpu.all_reduce_(planes[0:3])
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    _barrier(args, gpu)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, device)
+    return {"workload": "Scenes/cornell_crystal.scene %dx%d, %d spp split over %d GPUs, all-reduce of "
+                        "the colour planes" % (W, H, total, world),
+            "msamples_per_s": float(W) * H * total / elapsed / 1e6, "frame_ms": elapsed * 1e3,
+            "render_ms_rank0": (t1 - t0) * 1e3, "exchange_ms_rank0": (t2 - t1) * 1e3,
+            "exchange_bytes_per_rank": multigpu.exchange_bytes(W, H, world, features=False)}
+
+
+def config5_leg(ctx, args, rank, world, gpu, device):
+    """BASELINE.json configs[4]: Box_Grid 3840x2160 with features, samples split across the
+    ranks (313 per GPU: 2500 spp on eight), band-wise merge (all-to-all, halo rows included),
+    row-band denoiser N = 1 with BEST.txt, all-gather of the filtered bands."""
+    W, H = args.leg_width, args.leg_height
+    per_gpu = 313
+    total = min(2500, per_gpu * world) if world == 8 else per_gpu * world
+    raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", "Box_Grid.scene"),
+                                    W, H, args.depth, 0.005, True)
+    w = ptk.load_weights(os.path.join(ROOT, "data", "weights", "BEST.txt"))
+    ctx.set_constants(raw)
+    ctx.set_stream_id(rank)
+    planes = multigpu.device_planes(ctx, device)
+    n_local = multigpu.shard_spp(total, world, rank)
+    out = {}
+    for attempt in ("warm", "timed"):
+        ctx.reset()
+        ctx.synchronize()
+        _barrier(args, gpu)
+        t0 = time.perf_counter()
+        ctx.render(n_local if attempt == "timed" else 4, ptk.SEED_COUNTER)
+        t1 = time.perf_counter()
+        n_total, lo, hi = multigpu.merge_to_bands(planes, n_local if attempt == "timed" else 4,
+                                                  W, H, halo=3, ctx=ctx)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        multigpu.denoise_sharded(ctx, w, 1, device, n_total=n_total)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        band_ms = ctx.timing().denoise_ms
+        _barrier(args, gpu)
+        elapsed = _max_over_ranks(time.perf_counter() - t0, device)
+        post = _max_over_ranks(t3 - t1, device)
+        out = {"workload": "Scenes/Box_Grid.scene %dx%d with features, %d spp split over %d GPUs, "
+                           "band-wise merge + row-band denoise N=1 BEST.txt + gather" % (W, H, total, world),
+               "msamples_per_s": float(W) * H * total / elapsed / 1e6, "frame_ms": elapsed * 1e3,
+               "render_ms_rank0": (t1 - t0) * 1e3,
+               "denoise_frame_ms": post * 1e3,          # merge + band denoise + gather, max over ranks
+               "merge_ms_rank0": (t2 - t1) * 1e3, "band_denoise_and_gather_ms_rank0": (t3 - t2) * 1e3,
+               "band_denoise_kernels_ms_rank0": band_ms,
+               "merge_bytes_received_per_rank": multigpu.exchange_bytes(W, H, world, halo=3),
+               "gather_bytes_received_per_rank": int((world - 1) * 16 * W * (H // world + 1))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +300,10 @@ def main():
                     help="run the multi-rank exchange path even with one rank (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denoise-probe", action="store_true")
+    ap.add_argument("--no-multi-gpu-legs", action="store_true",
+                    help="skip the 3840x2160 config 4 / config 5 legs of a multi-rank run")
+    ap.add_argument("--leg-width", type=int, default=3840)
+    ap.add_argument("--leg-height", type=int, default=2160)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -238,24 +338,21 @@ def main():
     ctx.set_math_mode(ptk.MATH_FAST if args.math == "fast" else ptk.MATH_EXACT)
     ctx.set_stream_id(rank)
     planes = multigpu.device_planes(ctx, device) if use_dist else None
-    frame = torch.empty((3, W * H), dtype=torch.float32, device=device) if use_dist else None
 
     spp = args.spp_per_step
     kernel_ms = []
     kernel_rays = []
 
     def step():
-        ctx.render(spp, ptk.SEED_COUNTER)
+        ctx.render(spp, ptk.SEED_COUNTER)     # returns when the launch has finished
         t = ctx.timing()
         kernel_ms.append(t.render_ms)
         kernel_rays.append(t.render_rays)
+
+    def exchange():
+        # the frame's one accumulation exchange: colour sums over ranks, in place in HBM
         if use_dist:
-            # per-frame accumulation exchange: sum of the colour planes over ranks
-            frame.copy_(planes[0:3])
-            # the next render (on the context's own stream) rewrites these planes: let the
-            # snapshot finish first; the all-reduce itself overlaps the next step
-            torch.cuda.current_stream(device).synchronize()
-            multigpu.all_reduce_(frame)
+            multigpu.all_reduce_(planes[0:3])
 
     def fence():
         ctx.synchronize()
@@ -266,12 +363,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    exchange()                                # warms the collective up as well
+    ctx.reset()
     kernel_ms.clear()
     kernel_rays.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    exchange()
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -292,10 +392,19 @@ def main():
                         "maxDepth %d, device counter seeds, math=%s" % (
                             args.scene, W, H, spp, args.steps, args.depth, args.math),
             "samples_per_step_per_gpu": W * H * spp,
-            "exchange": "all-reduce of 3 colour planes per step" if use_dist else "none",
+            "exchange": ("one all-reduce of the 3 colour planes (%d bytes) at the end of the frame, "
+                         "inside the timed region" % (3 * W * H * 4)) if use_dist else "none",
         },
     }
+    legs = {}
+    if use_dist and not args.no_multi_gpu_legs:
+        for name, fn in (("config4", config4_leg), ("config5", config5_leg)):
+            try:
+                legs[name] = fn(ctx, args, rank, world, gpu, device)
+            except Exception as exc:   # a leg must not cost the run its result line
+                legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
+        out.update(legs)
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         samples_per_launch = float(W) * H * spp
         try:
@@ -339,7 +448,7 @@ def main():
             out["roofline"] = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_TFLOPS,
                                "unit": "TFLOP/s", "frac": None, "traffic": None,
                                "avg_launch_ms": avg_ms, "note": "op count unavailable: %s" % exc}
-        if world == 1:
+        if world == 1 and not args.force_dist:
             if not args.no_denoise_probe:
                 out["denoise"] = denoise_probe(ctx, W, H, args.depth)
                 out["scene_hierarchy"] = hierarchy_probe(ctx, W, H)

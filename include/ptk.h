@@ -95,7 +95,7 @@ typedef struct ptk_times {
     double exposure_ms;      /* reduce kernel of the last ptk_auto_exposure          */
     double features_ms;      /* feature + MLP kernel of the last ptk_denoise         */
     double filter_ms;        /* filter kernel of the last ptk_denoise                */
-    double denoise_ms;       /* features_ms + filter_ms (or the fused kernel)        */
+    double denoise_ms;       /* features_ms + filter_ms                              */
     uint64_t render_samples; /* width*height*spp of the last ptk_render              */
     uint64_t render_rays;    /* bounce rays traced by the last ptk_render            */
     double post_ms;          /* kernel of the last ptk_post_process                  */
@@ -268,9 +268,11 @@ int ptk_auto_exposure_static(const float* colour_planes_d, size_t pixels, int wi
  * neighbourhood features -> 36-10-10-7 MLP (weights in the file order of
  * DenoiserNN.cpp:1625-1663: w12[36*node+input], w23[10*node+input],
  * w34[10*node+input]) -> (2N+1)^2 clamp-to-edge cross-bilateral filter.
- * variant 0 = separate feature and filter kernels, 1 = fused kernel.
+ * variant must be 0 (a feature + MLP kernel, then a filter kernel; the argument
+ * is kept for binary compatibility: a single fused kernel was measured slower
+ * than the two launches and removed, and 1 is PTK_ERR_ARG).
  * Outputs (all optional): denoised rgb interleaved (3P), wcSum (P),
- * variances (7P, pixel-major), features (36P, pixel-major; variant 0 only). */
+ * variances (7P, pixel-major), features (36P, pixel-major). */
 int ptk_denoise(ptk_ctx* ctx, const float w12[360], const float w23[100], const float w34[70],
                 int n, int variant, float* denoised_3p, float* wc_sum_p, float* variances_7p,
                 float* features_36p);
@@ -293,8 +295,9 @@ int ptk_denoise_outputs_device(ptk_ctx* ctx, float** denoised_d, float** wc_sum_
  * transform of the frame held by the context.  display_metric selects the source
  * as the reference's displayMetric does: 0 colour / spp, 1 the last ptk_denoise
  * output, 2 (normal / spp + 1) / 2, 3 albedo1 / spp, 4 albedo2 / spp,
- * 5 directLight / spp, 6 1 / (worldPos / spp); 7 (the training target) is not
- * held by the hot path and is PTK_ERR_ARG.  Then / exposure and pow(., 1 / g)
+ * 5 directLight / spp, 6 1 / (worldPos / spp), 7 the training target set by
+ * ptk_save_target / ptk_set_target (CUDARender.cu:1006-1010, 1050-1052;
+ * PTK_ERR_STATE before one is set).  Then / exposure and pow(., 1 / g)
  * (within 1e-6 relative of powf).
  * post_screen (optional) receives the reference's postScreen: interleaved rgb,
  * 3 * P floats.  rgb8 (optional) receives what PT::SaveImage writes

@@ -1464,20 +1464,20 @@ int orc_load_weights(const char* path, float* w12, float* w23, float* w34)
 
 /* CUDAPostProcess (CUDARender.cu:959-1022): the display source of each metric
  * (CUDARender::PostProcess, 1024-1066), then / exposure, then pow(., 1/g).
- * `denoised` is the filter's output, interleaved (metric 1); metric 7 shows a
- * training target the hot path does not hold and is rejected. */
+ * `denoised` is the interleaved screen metrics 1 and 7 display as it is: the
+ * filter's output (denoisedCol) or the training target (targetCol). */
 int orc_post_process(const float* acc, const float* denoised, int width, int height,
                      int sample_count, int metric, float exposure, float gamma, float* post)
 {
     size_t P = (size_t)width * (size_t)height;
     float n = (float)sample_count;
-    if (metric < 0 || metric > 6 || (metric == 1 && !denoised)) return -1;
+    if (metric < 0 || metric > 7 || ((metric == 1 || metric == 7) && !denoised)) return -1;
     for (size_t i = 0; i < P; i++) {
         float c[3];
         for (int ch = 0; ch < 3; ch++) {
             switch (metric) {
             case 0: c[ch] = acc[(ORC_PL_COL + ch) * P + i] / n; break;
-            case 1: c[ch] = denoised[3 * i + ch]; break;
+            case 1: case 7: c[ch] = denoised[3 * i + ch]; break;
             case 2: c[ch] = (acc[(ORC_PL_NORMAL + ch) * P + i] / n + 1.0f) / 2.0f; break;
             case 3: c[ch] = acc[(ORC_PL_ALB1 + ch) * P + i] / n; break;
             case 4: c[ch] = acc[(ORC_PL_ALB2 + ch) * P + i] / n; break;

@@ -164,8 +164,9 @@ int orc_load_weights(const char* path, float* w12, float* w23, float* w34);
  * out[i] = its result for the nine values v[9 i .. 9 i + 8]. */
 void orc_mad_procedure(const float* v, size_t n, float* out);
 
-/* CUDAPostProcess for display metrics 0..6 (CUDARender.cu:959-1066): post is
- * interleaved rgb, P * 3 floats.  Returns -1 for an unsupported metric. */
+/* CUDAPostProcess for display metrics 0..7 (CUDARender.cu:959-1066): post is
+ * interleaved rgb, P * 3 floats; denoised_interleaved is the screen metrics 1
+ * (denoisedCol) and 7 (targetCol) display.  Returns -1 for an unsupported metric. */
 int orc_post_process(const float* planes, const float* denoised_interleaved, int width, int height,
                      int sample_count, int metric, float exposure, float gamma, float* post);
 /* PT::SaveImage quantisation, top row first (PT.cpp:484-501). */

@@ -28,9 +28,6 @@ namespace {
 #ifndef PTK_DN_WAVES_FILTER
 #define PTK_DN_WAVES_FILTER 3
 #endif
-#ifndef PTK_DN_WAVES_FUSED
-#define PTK_DN_WAVES_FUSED 3
-#endif
 constexpr int TW = 32, TH = 8;         // output tile
 constexpr int FH = 3;                  // feature halo (7x7 window)
 constexpr int FW = TW + 2 * FH;        // 38
@@ -666,47 +663,6 @@ void filter_strip_kernel(DenoiseArgs a)
     }
 }
 
-// ---- fused: features + MLP for the centre pixel, then the filter, one launch.
-template <int NFIX>
-__global__ __launch_bounds__(256, PTK_DN_WAVES_FUSED) void denoise_fused_kernel(DenoiseArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int W = a.width, H = a.height, N = NFIX > 0 ? NFIX : a.n;
-    const size_t P = (size_t)W * H;
-    const int SW = TW + 2 * N, SS = SW * (TH + 2 * N);
-    float* ptile = smem;
-    float* ftile = smem + PTILE_FLOATS;
-    const float n = (float)a.sample_count;
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    int x0, y0;
-    if (!tile_origin(a, x0, y0)) return;   // uniform over the workgroup, before any barrier
-    const int x = x0 + lx, y = y0 + ly;
-    const bool inside = x < W && y < a.row_end;
-    const size_t idx = inside ? (size_t)y * W + x : 0;
-    float sd[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
-
-    load_primary_tile(a.planes, P, W, H, x0, y0, n, ptile);
-    load_filter_tile(a.planes, P, W, H, x0, y0, N, n, ftile);
-    __syncthreads();
-    if (!inside) return;
-
-    float var[7];
-    const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    const float sd5[5] = {sd[1], sd[2], sd[3], sd[4], sd[5]};
-    features_and_mlp(ptile, ly, lx, sd5, 1.0f / n, w, nullptr, nullptr, P, idx, var);
-#pragma unroll
-    for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
-    float wsum[3], wc;
-    filter_pixel<NFIX>(ftile, SW, SS, ly, lx, N, sd, var, wsum, wc);
-    const float inv = 1.0f / wc;
-    a.denoised[idx] = wsum[0] * inv;
-    a.denoised[P + idx] = wsum[1] * inv;
-    a.denoised[2 * P + idx] = wsum[2] * inv;
-    a.wc_sum[idx] = wc;
-}
-
 size_t filter_lds_bytes(int N)
 {
     size_t sw = TW + 2 * (size_t)N, sh = TH + 2 * (size_t)N;
@@ -793,11 +749,4 @@ hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
 #endif
     if (a.n == 1) return launch_dyn(filter_kernel<1>, a, lds, stream);
     return launch_dyn(filter_kernel<0>, a, lds, stream);
-}
-
-hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream)
-{
-    size_t lds = filter_lds_bytes(a.n) + PTILE_FLOATS * sizeof(float);
-    if (a.n == 1) return launch_dyn(denoise_fused_kernel<1>, a, lds, stream);
-    return launch_dyn(denoise_fused_kernel<0>, a, lds, stream);
 }

@@ -22,7 +22,7 @@ __device__ __forceinline__ float source(const PostArgs& a, float n, int ch, floa
     float v;
     switch (a.metric) {   // uniform
     case 0: case 3: case 4: case 5: v = raw / n; break;
-    case 1: v = raw; break;
+    case 1: case 7: v = raw; break;
     case 2: v = (raw / n + 1.0f) / 2.0f; break;
     default: v = 1.0f / (raw / n); break;
     }
@@ -35,6 +35,7 @@ __device__ __forceinline__ const float* source_plane(const PostArgs& a, int ch)
     switch (a.metric) {
     case 0: return a.planes + (size_t)(PTK_PL_COL + ch) * a.pixels;
     case 1: return a.denoised + (size_t)ch * a.pixels;
+    case 7: return a.target + (size_t)ch * a.pixels;
     case 2: return a.planes + (size_t)(PTK_PL_NORMAL + ch) * a.pixels;
     case 3: return a.planes + (size_t)(PTK_PL_ALB1 + ch) * a.pixels;
     case 4: return a.planes + (size_t)(PTK_PL_ALB2 + ch) * a.pixels;

@@ -85,6 +85,7 @@ struct ptk_ctx {
     float* post_d = nullptr;          // 3 planes (allocated on the first ptk_post_process)
     uint8_t* rgb8_d = nullptr;        // 3 bytes per pixel (likewise)
     bool have_denoised = false;
+    bool have_features = false;       // planes 3..37 hold feature sums and statistics
     float* staging_h = nullptr;       // pinned, for layout conversion on read-back
     size_t staging_floats = 0;
 
@@ -736,8 +737,17 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
                              imp.size() * sizeof(int32_t)};
     uint64_t total = 0;
     for (int i = 0; i < 7; i++) {
-        HIP_TRY(hipMalloc(&c->big_alloc[i], bytes[i]));
-        HIP_TRY(hipMemcpyAsync(c->big_alloc[i], src[i], bytes[i], hipMemcpyHostToDevice, c->stream));
+        hipError_t e = hipMalloc(&c->big_alloc[i], bytes[i]);
+        const bool no_memory = e != hipSuccess;
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->big_alloc[i], src[i], bytes[i], hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            // copies queued so far read host vectors that die with this frame
+            (void)hipStreamSynchronize(c->stream);
+            free_big_scene(c);
+            return fail(no_memory ? PTK_ERR_NOMEM : PTK_ERR_HIP, "ptk_set_scene: table %d (%zu bytes): %s",
+                        i, bytes[i], hipGetErrorString(e));
+        }
         total += bytes[i];
     }
     c->big.nodes = (const BvhNode*)c->big_alloc[0];
@@ -805,6 +815,7 @@ int ptk_reset_accumulators(ptk_ctx* c)
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->planes_d, 0, PTK_N_PLANES * c->pixels * sizeof(float), c->stream));
     c->sample_count = 0;
+    c->have_features = false;
     return PTK_OK;
 }
 
@@ -916,6 +927,7 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     HIP_TRY(hipMemcpyAsync(&rays, c->rays_d, sizeof rays, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (rays_out) *rays_out = rays;
+    if (c->features && spp > 0) c->have_features = true;
     c->times.render_ms = render_ms;
     c->times.seed_ms = seed_ms;
     c->times.render_samples = (uint64_t)P * (uint64_t)spp;
@@ -954,6 +966,7 @@ int ptk_write_planes(ptk_ctx* c, int first_plane, int n_planes, const float* in,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->sample_count = sample_count;
+    if (first_plane + n_planes > PTK_PL_NORMAL) c->have_features = true;
     return PTK_OK;
 }
 
@@ -1085,10 +1098,13 @@ int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* 
     if (!c || !w12 || !w23 || !w34) return fail(PTK_ERR_ARG, "ptk_denoise: null argument");
     if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_denoise before ptk_set_constants");
     if (c->sample_count < 1) return fail(PTK_ERR_STATE, "ptk_denoise: no samples accumulated");
+    if (!c->have_features)
+        return fail(PTK_ERR_STATE, "ptk_denoise: the feature planes were not accumulated (render "
+                    "with want_denoise_features, or write planes 3..37)");
     if (n < 0 || n > 8) return fail(PTK_ERR_ARG, "ptk_denoise: N %d outside [0,8]", n);
-    if (variant != 0 && variant != 1) return fail(PTK_ERR_ARG, "ptk_denoise: variant %d", variant);
-    if (variant == 1 && want_features)
-        return fail(PTK_ERR_ARG, "ptk_denoise: the fused variant does not materialise features");
+    if (variant != 0)
+        return fail(PTK_ERR_ARG, "ptk_denoise: variant %d (only 0, the two-pass denoiser, exists)",
+                    variant);
     if (row_begin < 0 || row_end > c->height || row_begin > row_end)
         return fail(PTK_ERR_ARG, "ptk_denoise: rows [%d,%d) outside [0,%d)", row_begin, row_end,
                     c->height);
@@ -1127,25 +1143,17 @@ int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* 
     a.row_begin = row_begin;
     a.row_end = row_end;
     if (row_begin == row_end) return PTK_OK;
+    c->have_denoised = false;   // until the launches below are queued
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(ptk_launch_features_mlp(a, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    c->times.features_ms = elapsed_ms(c);
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(ptk_launch_filter(a, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    c->times.filter_ms = elapsed_ms(c);
+    c->times.denoise_ms = c->times.features_ms + c->times.filter_ms;
     c->have_denoised = true;
-    if (variant == 0) {
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        HIP_TRY(ptk_launch_features_mlp(a, c->stream));
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        c->times.features_ms = elapsed_ms(c);
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        HIP_TRY(ptk_launch_filter(a, c->stream));
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        c->times.filter_ms = elapsed_ms(c);
-        c->times.denoise_ms = c->times.features_ms + c->times.filter_ms;
-    } else {
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        HIP_TRY(ptk_launch_denoise_fused(a, c->stream));
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        c->times.denoise_ms = elapsed_ms(c);
-        c->times.features_ms = 0.0;
-        c->times.filter_ms = 0.0;
-    }
     return PTK_OK;
 }
 }  // namespace
@@ -1280,11 +1288,14 @@ int ptk_post_process(ptk_ctx* c, int metric, float exposure, float g, float* pos
 {
     if (!c) return fail(PTK_ERR_ARG, "ptk_post_process: null context");
     if (!c->planes_d) return fail(PTK_ERR_STATE, "ptk_post_process before ptk_set_constants");
-    if (metric < 0 || metric > 6)
-        return fail(PTK_ERR_ARG, "ptk_post_process: display metric %d (0..6 supported)", metric);
+    if (metric < 0 || metric > 7)
+        return fail(PTK_ERR_ARG, "ptk_post_process: display metric %d outside [0,7]", metric);
     if (metric == 1 && !c->have_denoised)
         return fail(PTK_ERR_STATE, "ptk_post_process: metric 1 before ptk_denoise");
-    if (metric != 1 && c->sample_count < 1)
+    if (metric == 7 && !c->have_target)
+        return fail(PTK_ERR_STATE,
+                    "ptk_post_process: metric 7 before ptk_save_target / ptk_set_target");
+    if (metric != 1 && metric != 7 && c->sample_count < 1)
         return fail(PTK_ERR_STATE, "ptk_post_process: no samples accumulated");
     int rc = bind(c);
     if (rc != PTK_OK) return rc;
@@ -1295,6 +1306,7 @@ int ptk_post_process(ptk_ctx* c, int metric, float exposure, float g, float* pos
     PostArgs a;
     a.planes = c->planes_d;
     a.denoised = c->denoised_d;
+    a.target = c->target_d;
     a.post = c->post_d;
     a.rgb8 = rgb8 ? c->rgb8_d : nullptr;
     a.pixels = P;

@@ -152,6 +152,7 @@ hipError_t ptk_launch_refresh_std_dev(float* planes, size_t pixels, int sample_c
 struct PostArgs {
     const float* planes;     // accumulators
     const float* denoised;   // 3 planes (metric 1)
+    const float* target;     // 3 planes (metric 7: the training target)
     float* post;             // 3 planes out
     uint8_t* rgb8;           // 3 bytes per pixel, top row first; may be null
     size_t pixels;
@@ -201,4 +202,3 @@ hipError_t ptk_launch_train(const TrainArgs& a, hipStream_t stream);
 hipError_t ptk_launch_save_target(const float* planes, float* target, size_t pixels,
                                   int sample_count, hipStream_t stream);
 hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream);
-hipError_t ptk_launch_denoise_fused(const DenoiseArgs& a, hipStream_t stream);

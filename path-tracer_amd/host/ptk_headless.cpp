@@ -18,7 +18,7 @@ static void usage()
                  "       [--rand-samp F] [--seed HEX0,HEX1 | --counter-seeds] [--fast]\n"
                  "       [--auto-exposure] [--denoise N --weights FILE] [--device K]\n"
                  "       [--ppm OUT.ppm] [--dump PREFIX]\n"
-                 "       [--train EPOCHS --train-spp N --lr-exp X --save-weights FILE]\n"
+                 "       [--train EPOCHS --train-spp N --lr-exp X --save-weights FILE --error-log FILE]\n"
                  "         (the rendered frame becomes the target; needs --denoise N)\n");
 }
 
@@ -33,6 +33,7 @@ int main(int argc, char** argv)
 {
     std::string scene, weights, ppm, prefix, save_weights;
     int epochs = 0, train_spp = 4;
+    std::string error_log;
     float lr_exp = 5.0f;
     int W = 1536, H = 864, spp = 16, depth = 4, nwin = -1, device = 0;
     float rand_samp = 0.005f;
@@ -61,6 +62,7 @@ int main(int argc, char** argv)
         else if (a == "--dump") prefix = next();
         else if (a == "--train") epochs = std::atoi(next());
         else if (a == "--train-spp") train_spp = std::atoi(next());
+        else if (a == "--error-log") error_log = next();
         else if (a == "--lr-exp") lr_exp = (float)std::atof(next());
         else if (a == "--save-weights") save_weights = next();
         else { usage(); return 2; }
@@ -99,6 +101,9 @@ int main(int argc, char** argv)
         }
         st.denoiserNN.samplesWhenTraining = train_spp;
         st.denoiserNN.lRateInt = st.denoiserNN.lRateIntMax = lr_exp;
+        // continue from --weights (random weights without it); the log goes next to the other outputs
+        st.denoiserNN.trainedWeightsPath = weights;
+        st.denoiserNN.errorLogPath = error_log;
         st.denoiserNN.InitTraining();
         for (int e = 0; e < epochs && st.ok(); e++) {
             st.denoiserNN.TrainNN();
@@ -106,7 +111,9 @@ int main(int argc, char** argv)
                         st.denoiserNN.learningRate, st.denoiserNN.epochTime);
         }
         if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
-        if (!save_weights.empty()) st.denoiserNN.OutputWeights(save_weights);
+        st.denoiserNN.trainedWeightsPath = save_weights;   // empty: keep them in memory only
+        st.denoiserNN.EndTraining();
+        std::printf("training: %d epochs, %.3f ms\n", epochs, st.denoiserNN.trainingTime);
         weights.clear();   // the trained weights are in place for the denoise below
     }
     if (nwin >= 0) {

@@ -500,15 +500,39 @@ void DenoiserNN::InitTraining()
 {
     if (!st_->ctx) { st_->lastError = "DenoiserNN::InitTraining before UpdateConstants"; return; }
     training = true;
+    trainingTime = 0.0;
     st_->check(ptk_save_target(st_->ctx), "ptk_save_target");
-    if (!st_->weightsLoaded) RandomizeWeights();
+    if (trainedWeightsPath.empty() || !LoadWeights(trainedWeightsPath)) RandomizeWeights();
     st_->weightsLoaded = true;
     trainingEpoch = 0;
+    if (errorLogPath.empty()) return;
+    std::ofstream log(errorLogPath);
+    if (log.is_open())
+        log << "Res: (" << st_->xRes << "x" << st_->yRes << ") Samples: " << samplesWhenTraining
+            << " L Rate: " << learningRate << "," << std::endl;
+}
+
+void DenoiserNN::AppendTrainingFile()
+{
+    if (errorLogPath.empty()) return;
+    std::ofstream log(errorLogPath, std::ios_base::app);
+    if (log.is_open()) log << relMSE << "," << std::endl;
+}
+
+void DenoiserNN::EndTraining()
+{
+    training = false;
+    if (!errorLogPath.empty()) {
+        std::ofstream log(errorLogPath, std::ios_base::app);
+        if (log.is_open()) log << trainingTime << std::endl;
+    }
+    if (!trainedWeightsPath.empty()) OutputWeights(trainedWeightsPath);
 }
 
 void DenoiserNN::TrainNN()
 {
     if (!st_->ctx) { st_->lastError = "DenoiserNN::TrainNN before UpdateConstants"; return; }
+    const auto t0 = std::chrono::high_resolution_clock::now();
     float inv = lRateInt;
     if (trainingLimitBool)
         inv = lRateInt + (lRateIntMax - lRateInt) * ((float)trainingEpoch / (float)trainingCount);
@@ -518,13 +542,16 @@ void DenoiserNN::TrainNN()
     st_->sampleCount = 0;
     st_->renderer.Render(samplesWhenTraining);
     if (!st_->ok()) return;
+    // denoise, relMSE (of the weights before the update) and back-prop in one device call
     st_->check(ptk_train_step(st_->ctx, onetwo, twothree, threefour, st_->denoisingN, learningRate,
                               &relMSE),
                "ptk_train_step");
     if (!st_->ok()) return;
-    ptk_times t;
-    if (ptk_timing(st_->ctx, &t) == PTK_OK) epochTime = t.denoise_ms + t.train_ms;
+    AppendTrainingFile();
     trainingEpoch++;
+    epochTime = std::chrono::duration<double, std::milli>(
+                    std::chrono::high_resolution_clock::now() - t0).count();
+    trainingTime += epochTime;
     if (trainingLimitBool && trainingEpoch == trainingCount) training = false;
 }
 
@@ -707,6 +734,36 @@ extern "C" int ptkhost_resave_weights(const char* in_path, const char* out_path)
     ptkhost::HostState st;
     if (!st.denoiserNN.LoadWeights(in_path)) return -1;
     st.denoiserNN.OutputWeights(out_path);
+    return 0;
+}
+
+// Writes a training log with the façade's own formatting (header, one line per epoch,
+// total time) without touching a GPU: the on-disk format build/TrainingVisualizer.py reads.
+extern "C" int ptkhost_write_training_log(const char* path, int width, int height, int samples,
+                                          float learning_rate, const float* rel_mse, int epochs,
+                                          double training_time_ms)
+{
+    if (!path || (epochs > 0 && !rel_mse)) return -1;
+    ptkhost::HostState st;
+    st.xRes = width;
+    st.yRes = height;
+    ptkhost::DenoiserNN& nn = st.denoiserNN;
+    nn.errorLogPath = path;
+    nn.trainedWeightsPath.clear();
+    nn.samplesWhenTraining = samples;
+    nn.learningRate = learning_rate;
+    {   // InitTraining's header line
+        std::ofstream log(nn.errorLogPath);
+        if (!log.is_open()) return -1;
+        log << "Res: (" << st.xRes << "x" << st.yRes << ") Samples: " << nn.samplesWhenTraining
+            << " L Rate: " << nn.learningRate << "," << std::endl;
+    }
+    for (int e = 0; e < epochs; e++) {
+        nn.relMSE = rel_mse[e];
+        nn.AppendTrainingFile();
+    }
+    nn.trainingTime = training_time_ms;
+    nn.EndTraining();
     return 0;
 }
 

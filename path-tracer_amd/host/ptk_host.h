@@ -94,18 +94,28 @@ public:
     float onetwo[360] = {0}, twothree[100] = {0}, threefour[80] = {0};
 
     // Training (DenoiserNN.cpp:1476-1563).  InitTraining takes the current frame
-    // as the target (Denoiser::saveTargetCol) and keeps the loaded weights, or
-    // randomises them when none are loaded; TrainNN is one epoch: a fresh frame
+    // as the target (Denoiser::saveTargetCol) and loads the weights to continue
+    // from, or randomises them when that file cannot be read; TrainNN is one epoch: a fresh frame
     // of samplesWhenTraining samples, denoise + relMSE + back-prop in one
     // device call (ptk_train_step), epoch counter and learning-rate schedule.
-    void InitTraining();
-    void TrainNN();
+    void InitTraining();                          // DenoiserNN.cpp:1476-1499
+    void TrainNN();                               // DenoiserNN.cpp:1520-1563
+    void AppendTrainingFile();                    // DenoiserNN.cpp:1500-1506
+    void EndTraining();                           // DenoiserNN.cpp:1507-1518
     void RandomizeWeights();                      // DenoiserNN.cpp:1591-1601
+    // The reference reads and writes "../Weights/NNWeights.txt" and "ErrorLog.txt"
+    // relative to its working directory; the same names are the defaults here.
+    // InitTraining loads trainedWeightsPath (randomising on failure) and writes the
+    // log's header line; every epoch appends its relMSE; EndTraining appends the
+    // total time in ms and saves the weights.  An empty path skips that file.
+    std::string trainedWeightsPath = "../Weights/NNWeights.txt";
+    std::string errorLogPath = "ErrorLog.txt";
+    double trainingTime = 0.0;                    // ms, sum of epochTime
     bool training = false, trainingLimitBool = false;
     int trainingEpoch = 0, trainingCount = 0, samplesWhenTraining = 4;
     float lRateInt = 5.0f, lRateIntMax = 5.0f;    // learningRate = 10^-lRateInt
     float learningRate = 0.0001f, relMSE = 0.0f;
-    double epochTime = 0.0;                       // ms, device time of the reductions
+    double epochTime = 0.0;                       // ms, wall clock of the epoch (render included)
 
 private:
     HostState* st_;

@@ -118,12 +118,18 @@ def test_headless_training_epochs(tmp_path):
     cmd = [HEADLESS, "--scene", scene_path("cornell"), "--res", "96x54", "--spp", "64",
            "--counter-seeds", "--denoise", "1", "--weights", weights_path("box_grid"),
            "--train", "3", "--train-spp", "4", "--lr-exp", "4", "--save-weights", out_w,
-           "--ppm", str(tmp_path / "t.ppm")]
+           "--error-log", str(tmp_path / "ErrorLog.txt"), "--ppm", str(tmp_path / "t.ppm")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     rel = [float(l.split("relMSE")[1].split()[0]) for l in r.stdout.splitlines()
            if l.startswith("epoch")]
     assert len(rel) == 3 and all(np.isfinite(rel)) and all(x > 0 for x in rel)
+    # the training log (DenoiserNN.cpp:1492-1514): header, one relMSE per epoch, total ms
+    log = open(str(tmp_path / "ErrorLog.txt")).read().split("\n")
+    assert log[0].startswith("Res: (96x54) Samples: 4 L Rate: ") and log[0].endswith(",")
+    assert [float(l.rstrip(",")) for l in log[1:4]] == pytest.approx(rel, rel=1e-5)
+    assert all(l.endswith(",") for l in log[1:4])
+    assert float(log[4]) > 0 and log[5] == ""
     w0, w1 = ptk.load_weights(weights_path("box_grid")), ptk.load_weights(out_w)
     assert all(np.isfinite(b).all() for b in w1)
     assert any(not np.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(w0, w1))

@@ -35,13 +35,24 @@ def _worker(rank, world, port, out_dir):
     n_local = multigpu.shard_spp(TOTAL_SPP, world, rank)
     ctx.render(n_local, ptk.SEED_COUNTER)
     planes = multigpu.device_planes(ctx, device)
-    n_total = multigpu.merge_planes(planes, n_local)
+    own = planes.clone()
+    # (a) whole-frame merge (all-reduce), then the row-band denoiser
+    n_total = multigpu.merge_planes(planes, n_local, ctx=ctx)
     torch.cuda.synchronize()
-    ctx.sample_count = n_total
-    den = multigpu.denoise_sharded(ctx, w, NWIN, device, variant=rank % 2)
+    assert ctx.sample_count == n_total
+    den = multigpu.denoise_sharded(ctx, w, NWIN, device, n_total=n_total)
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), planes=planes.cpu().numpy(),
-             denoised=den.cpu().numpy(), n_total=n_total)
+    merged, den_a = planes.cpu().numpy(), den.cpu().numpy()
+    # (b) band-wise merge (all-to-all, halo rows included), then the same denoiser
+    planes.copy_(own)
+    torch.cuda.synchronize()
+    ctx.sample_count = n_local
+    n_b, lo, hi = multigpu.merge_to_bands(planes, n_local, W, H, halo=max(3, NWIN), ctx=ctx)
+    den = multigpu.denoise_sharded(ctx, w, NWIN, device, n_total=n_b)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), planes=merged, denoised=den_a,
+             n_total=n_total, banded=planes.cpu().numpy(), denoised_b=den.cpu().numpy(),
+             span=np.array([lo, hi]))
     ctx.close()
     dist.destroy_process_group()
 
@@ -57,9 +68,16 @@ def test_two_ranks_on_one_gpu_match_a_single_context(tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     assert int(r0["n_total"]) == TOTAL_SPP == int(r1["n_total"])
     assert np.array_equal(r0["planes"], r1["planes"], equal_nan=True)
-    # bands were filtered by different variants (two-pass on rank 0, fused on rank 1);
-    # after the exchange both ranks hold the same full image
+    # after the gather both ranks hold the same full image
     assert np.array_equal(r0["denoised"], r1["denoised"], equal_nan=True)
+    # the band-wise exchange gives each rank the same merged values on its span, and the
+    # same denoised frame
+    for r in (r0, r1):
+        lo, hi = (int(x) for x in r["span"])
+        a = r["banded"].reshape(38, H, W)[:, lo:hi]
+        b = r["planes"].reshape(38, H, W)[:, lo:hi]
+        assert np.array_equal(a, b, equal_nan=True)
+        assert np.array_equal(r["denoised_b"], r0["denoised"], equal_nan=True)
 
     # the same job in one process: render each stream, merge by the same rule on the host
     raw, _, _ = ptk.scene_constants(scene_path("MultiLightGlass"), W, H, 4, 0.005, True)
@@ -90,10 +108,5 @@ def test_two_ranks_on_one_gpu_match_a_single_context(tmp_path):
     full = ctx.denoise(w, NWIN, 0)
     ctx.close()
     ref = full["denoised"].T
-    y0, y1 = multigpu.row_band(H, world, 0)
-    band0 = np.zeros(H * W, bool)
-    band0[y0 * W:y1 * W] = True
-    # rank 0's band: same two-pass kernels, bit-identical; rank 1's band: the fused kernel
-    assert np.array_equal(r0["denoised"][:, band0], ref[:, band0], equal_nan=True)
-    a, b = r0["denoised"][:, ~band0].astype(np.float64), ref[:, ~band0].astype(np.float64)
-    assert np.all(np.abs(a - b) <= 2e-5 * np.abs(b) + 1e-7)
+    # the same two-pass kernels on the same planes: bit-identical in both bands
+    assert np.array_equal(r0["denoised"], ref, equal_nan=True)

@@ -143,9 +143,8 @@ def test_read_accumulators_uses_the_reference_layout(ctx):
     assert np.array_equal(acc["stdDev"], ref[32:38].T)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("nwin", [1, 3])
-def test_denoiser_matches_golden(ctx, variant, nwin, oracle):
+def test_denoiser_matches_golden(ctx, nwin, oracle, variant=0):
     g = np.load(os.path.join(GOLDEN, "denoise_MultiLightGlass_128x72.npz"))
     O = oracle
     sc = O.load_scene(scene_path("MultiLightGlass"))
@@ -179,11 +178,13 @@ def test_denoiser_odd_sizes_and_edges(ctx, oracle):
     ctx.write_planes(acc, n)
     for nwin in (0, 1, 2, 5):
         den, wc = O.filter(acc, var, W, H, n, nwin)
-        for variant in (0, 1):
-            r = ctx.denoise(w, nwin, variant)
-            assert _rel_ok(r["variances"], var, 2e-5).all()
-            assert _rel_ok(r["denoised"], den, 5e-5).all()
-            assert _rel_ok(r["wcSum"], wc, 5e-5).all()
+        r = ctx.denoise(w, nwin, 0)
+        assert _rel_ok(r["variances"], var, 2e-5).all()
+        assert _rel_ok(r["denoised"], den, 5e-5).all()
+        assert _rel_ok(r["wcSum"], wc, 5e-5).all()
+    import ptk
+    with pytest.raises(ptk.PtkError, match="variant"):
+        ctx.denoise(w, 1, 1)            # the fused single-kernel variant no longer exists
 
 
 def test_render_odd_sizes_depths_and_empty_scene(ctx, oracle):
@@ -404,7 +405,7 @@ def test_denoise_row_bands_tile_the_full_result(ctx, oracle):
     ctx.set_constants(O.build_constants(sc, W, H, 4, 0.005, True))
     w = O.load_weights(weights_path("BEST"))
     ctx.render(16, ptk.SEED_COUNTER)
-    for variant in (0, 1):
+    for variant in (0,):
         full = ctx.denoise(w, 2, variant)
         den, wc = multigpu.device_denoised(ctx, torch.device("cuda", 0))
         den.zero_()
@@ -423,8 +424,7 @@ def test_denoise_row_bands_tile_the_full_result(ctx, oracle):
 
 def test_full_size_denoise_properties(ctx, oracle):
     """1920x1080, 16 spp with features, BEST.txt: the eight row bands of an 8-GPU split tile
-    the whole-frame result bit for bit; the fused and the two-pass forms agree to rounding;
-    the bandwidths of twelve random 48x48 crops recomputed on the CPU from the read-back
+    the whole-frame result bit for bit; the bandwidths of twelve random 48x48 crops recomputed on the CPU from the read-back
     accumulators agree within the small-frame tolerance."""
     import ptk
     import torch
@@ -436,10 +436,7 @@ def test_full_size_denoise_properties(ctx, oracle):
     w = O.load_weights(weights_path("BEST"))
     ctx.render(16, ptk.SEED_COUNTER)
     full = ctx.denoise(w, 1, 0)
-    fused = ctx.denoise(w, 1, 1)
-    ok = np.isfinite(full["denoised"]) & np.isfinite(fused["denoised"])
-    assert ok.mean() > 0.999
-    assert np.allclose(fused["denoised"][ok], full["denoised"][ok], rtol=2e-5, atol=1e-7)
+    assert np.isfinite(full["denoised"]).mean() > 0.999
     den, wc = multigpu.device_denoised(ctx, torch.device("cuda", 0))
     den.zero_()
     wc.zero_()
@@ -466,7 +463,7 @@ def test_full_size_denoise_properties(ctx, oracle):
 
 
 def test_post_process_matches_the_display_transform(ctx, oracle):
-    """Display metrics 0..6: float screen within 2e-6 relative of the CPU restatement (the
+    """Display metrics 0..7: float screen within 2e-6 relative of the CPU restatement (the
     gamma power is exp2(log2(v) / g) on the hardware units here, libm's powf there); 8-bit
     output identical except where a value sits within that distance of a quantisation step."""
     import ptk
@@ -490,8 +487,22 @@ def test_post_process_matches_the_display_transform(ctx, oracle):
         assert np.abs(rgb.astype(int) - ref8.astype(int)).max() <= 1
         # the library's own float screen quantises to exactly its 8-bit output
         assert np.array_equal(rgb, O.quantise8(post, W, H))
-    with pytest.raises(ptk.PtkError):
+    # metric 7: the training target (CUDARender.cu:1006-1010), once one is held
+    with pytest.raises(ptk.PtkError, match="metric 7"):
         ctx.post_process(7, 1.0, 2.2)
+    ctx.save_target()
+    target = np.ascontiguousarray(planes[0:3].T / np.float32(6))
+    for exposure, g in ((1.0, 2.2), (0.6, 1.8)):
+        ref = O.post_process(planes, target, W, H, 6, 7, exposure, g)
+        post, rgb = ctx.post_process(7, exposure, g, want_rgb8=True)
+        assert _rel_ok(post, ref, 2e-6).all()
+        assert np.array_equal(rgb, O.quantise8(post, W, H))
+    custom = np.random.default_rng(3).random((W * H, 3), dtype=np.float32)
+    ctx.set_target(custom)
+    post, _ = ctx.post_process(7, 1.0, 1.0)
+    assert _rel_ok(post, custom, 2e-6).all()
+    with pytest.raises(ptk.PtkError):
+        ctx.post_process(8, 1.0, 2.2)
     assert ctx.timing().post_ms > 0.0
 
 

@@ -19,6 +19,10 @@ def test_scene_survives_a_save_and_reload(path, tmp_path, oracle):
     out1, out2 = str(tmp_path / "a.scene"), str(tmp_path / "b.scene")
     ptk.resave_scene(path, out1)
     ptk.resave_scene(out1, out2)
+    # data/scenes holds the reference's own Scenes/*.scene, which are outputs of its
+    # Scene::SaveScene (headers/Scene.h:226-274): loading one and saving it again must
+    # reproduce the file byte for byte
+    assert open(out1, "rb").read() == open(path, "rb").read()
     assert open(out1).read() == open(out2).read()           # the writer is a fixed point
     a = ptk.scene_constants(path, 320, 180, 4, 0.005, True)
     b = ptk.scene_constants(out1, 320, 180, 4, 0.005, True)
@@ -35,6 +39,9 @@ def test_weights_survive_a_save_and_reload(path, tmp_path, oracle):
     out1, out2 = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
     ptk.resave_weights(path, out1)
     ptk.resave_weights(out1, out2)
+    # data/weights holds the reference's own Weights/*.txt, outputs of its OutputWeights
+    # (DenoiserNN.cpp:1603-1624): a load and a save reproduce the file byte for byte
+    assert open(out1, "rb").read() == open(path, "rb").read()
     w0, w1, w2 = ptk.load_weights(path), ptk.load_weights(out1), ptk.load_weights(out2)
     for x, y, z in zip(w0, w1, w2):
         # six significant digits are written (DenoiserNN.cpp:1603-1624)
@@ -43,6 +50,32 @@ def test_weights_survive_a_save_and_reload(path, tmp_path, oracle):
     assert len(open(out1).read().strip().split("\n")) == 3
     for x, y in zip(w0, oracle.load_weights(path)):
         assert np.array_equal(x, y)
+
+
+def test_training_log_reproduces_the_reference_file(tmp_path):
+    """tests/golden/ErrorLog.txt is the reference's own build/ErrorLog.txt (one training run:
+    header, relMSE per epoch, total time; DenoiserNN.cpp:1492-1514).  Writing the same run
+    through the facade's InitTraining header / AppendTrainingFile / EndTraining formatting
+    gives the same bytes."""
+    import ctypes as C
+    import ptk
+    ref = open(os.path.join(ROOT, "tests", "golden", "ErrorLog.txt")).read()
+    lines = ref.split("\n")
+    assert lines[0] == "Res: (480x270) Samples: 8 L Rate: 0.0001,"
+    body = [l for l in lines[1:] if l]
+    rel = np.float32([float(l.rstrip(",")) for l in body[:-1]])
+    assert all(l.endswith(",") for l in body[:-1]) and not body[-1].endswith(",")
+    H = ptk._load_host()
+    H.ptkhost_write_training_log.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             C.POINTER(C.c_float), C.c_int, C.c_double]
+    H.ptkhost_write_training_log.restype = C.c_int
+    out = str(tmp_path / "ErrorLog.txt")
+    rc = H.ptkhost_write_training_log(os.fsencode(out), 480, 270, 8, C.c_float(0.0001),
+                                      rel.ctypes.data_as(C.POINTER(C.c_float)), len(rel),
+                                      float(body[-1]))
+    assert rc == 0
+    assert open(out).read() == ref
+    assert len(rel) == 53
 
 
 def test_missing_files_are_reported(tmp_path):

@@ -26,10 +26,24 @@ def _worker(rank, world, port, W, H, total_spp, out_dir):
     # each rank continues a different seed stream (stands in for the per-GPU stream id)
     seed = (PIN_SEED[0] + 0x1000 * rank, PIN_SEED[1] ^ (0xABCDEF * (rank + 1)))
     O.render(consts, acc, n_local, 0, seed, threads=2)
-    planes = torch.from_numpy(acc)
+    planes = torch.from_numpy(acc.copy())
     n_total = multigpu.merge_planes(planes, n_local)
     np.save(os.path.join(out_dir, "merged_%d.npy" % rank), planes.numpy())
     assert n_total == total_spp
+    # the band-wise exchange: this rank's band and halo rows get the same merged values
+    banded = torch.from_numpy(acc.copy())
+    halo = 3
+    n_b, lo, hi = multigpu.merge_to_bands(banded, n_local, W, H, halo=halo)
+    assert n_b == total_spp and (lo, hi) == multigpu.band_with_halo(H, world, rank, halo)
+    a = banded.view(38, H, W)[:, lo:hi].numpy()
+    b = planes.view(38, H, W)[:, lo:hi].numpy()
+    assert np.array_equal(a, b, equal_nan=True)
+    # rows outside the span keep this rank's own values
+    own = torch.from_numpy(acc).view(38, H, W)
+    if lo > 0:
+        assert np.array_equal(banded.view(38, H, W)[:, :lo].numpy(), own[:, :lo].numpy(), equal_nan=True)
+    if hi < H:
+        assert np.array_equal(banded.view(38, H, W)[:, hi:].numpy(), own[:, hi:].numpy(), equal_nan=True)
     dist.destroy_process_group()
 
 
@@ -43,6 +57,13 @@ def test_shard_spp_and_row_bands_partition_the_work():
         bands = [multigpu.row_band(H, world, r) for r in range(world)]
         assert bands[0][0] == 0 and bands[-1][1] == H
         assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+        for r, (y0, y1) in enumerate(bands):
+            assert multigpu.band_with_halo(H, world, r, 3) == (max(0, y0 - 3), min(H, y1 + 3))
+    # bytes a rank receives per frame at 4K on eight GPUs: the band-wise exchange moves half
+    # of what a ring all-reduce of the same 32 planes would
+    band = multigpu.exchange_bytes(3840, 2160, 8, halo=3)
+    ring = 2 * 7 / 8 * 32 * 3840 * 2160 * 4
+    assert 0.45 * ring < band < 0.55 * ring
 
 
 def test_two_rank_merge_matches_a_single_stream(tmp_path, oracle):

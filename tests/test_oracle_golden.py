@@ -96,7 +96,12 @@ def test_post_process_metric0_is_the_tonemap(oracle):
     with pytest.raises(ValueError):
         oracle.post_process(acc, None, 64, 36, 8, 1, 1.0, 2.2)    # metric 1 needs a denoised image
     with pytest.raises(ValueError):
-        oracle.post_process(acc, None, 64, 36, 8, 7, 1.0, 2.2)
+        oracle.post_process(acc, None, 64, 36, 8, 7, 1.0, 2.2)    # so does metric 7 (the target)
+    with pytest.raises(ValueError):
+        oracle.post_process(acc, None, 64, 36, 8, 8, 1.0, 2.2)
+    # metrics 1 and 7 display the given screen as it is
+    screen = np.ascontiguousarray(acc[0:3].T / 8)
+    assert np.array_equal(oracle.post_process(acc, screen, 64, 36, 8, 7, 0.8, 2.2), post)
     # metric 2 maps normals from [-1, 1] to [0, 1]
     n = oracle.post_process(acc, None, 64, 36, 8, 2, 1.0, 1.0)
     assert np.nanmin(n) >= -1e-6 and np.nanmax(n) <= 1.0 + 1e-6
