@@ -470,35 +470,55 @@ DEV FilterCoef make_coef(const float* sd, const float* var)
     return c;
 }
 
-// One filter tap at tile word offset e (Denoiser.cpp:301-348): the product of
-// the seven Gaussians is one exp of the summed exponents.
-DEV void filter_tap(const float* t, int SS, int e, float dist_idx, const float (&pv)[16],
-                    const FilterCoef& c, float (&wsum)[3], float& wc)
+// One filter tap (Denoiser.cpp:301-348): the product of the seven Gaussians is one exp of
+// the summed exponents.  `nb` supplies the neighbour: diff(k) = its value k minus the centre
+// pixel's, sd0_sum(s) = s + its stdDev[0], accumulate(w, wsum) adds its colour times w.
+template <class Neighbour>
+DEV void filter_tap_core(const Neighbour& nb, float dist_idx, const FilterCoef& c,
+                         float (&wsum)[3], float& wc)
 {
-    float q[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) q[k] = t[k * SS + e];
-    const float sd0q = t[16 * SS + e];
     float d2[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        float dx = q[3 * k] - pv[3 * k], dy = q[3 * k + 1] - pv[3 * k + 1],
-              dz = q[3 * k + 2] - pv[3 * k + 2];
+        float dx = nb.diff(3 * k), dy = nb.diff(3 * k + 1), dz = nb.diff(3 * k + 2);
         d2[k] = dx * dx + dy * dy + dz * dz;
     }
-    float ddl = q[15] - pv[15];
+    float ddl = nb.diff(15);
     float arg = dist_idx * c.inv_idx;
-    arg += d2[0] * fast_rcp((c.sd0 + sd0q) * c.col_scale + 0.000001f);
+    arg += d2[0] * fast_rcp(nb.sd0_sum(c.sd0) * c.col_scale + 0.000001f);
     arg += d2[1] * c.inv_nrm;
     arg += d2[2] * c.inv_a1;
     arg += d2[3] * c.inv_a2;
     arg += d2[4] * c.inv_wp;
     arg += ddl * ddl * c.inv_dl;
     float w = fast_exp(-arg);
-    wsum[0] += q[0] * w;
-    wsum[1] += q[1] * w;
-    wsum[2] += q[2] * w;
+    nb.accumulate(w, wsum);
     wc += w;
+}
+
+// The neighbour whose 16 values and stdDev[0] are in registers.
+struct NeighbourValues {
+    const float (&q)[16];
+    float sd0q;
+    const float (&pv)[16];
+    DEV float diff(int k) const { return q[k] - pv[k]; }
+    DEV float sd0_sum(float s) const { return s + sd0q; }
+    DEV void accumulate(float w, float (&wsum)[3]) const
+    {
+        wsum[0] += q[0] * w;
+        wsum[1] += q[1] * w;
+        wsum[2] += q[2] * w;
+    }
+};
+
+// The tap whose values sit at word offset e of an LDS tile with planes SS words apart.
+DEV void filter_tap(const float* t, int SS, int e, float dist_idx, const float (&pv)[16],
+                    const FilterCoef& c, float (&wsum)[3], float& wc)
+{
+    float q[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[k] = t[k * SS + e];
+    filter_tap_core(NeighbourValues{q, t[16 * SS + e], pv}, dist_idx, c, wsum, wc);
 }
 
 // All taps of the pixel at tile coordinates (ly, lx).  NFIX > 0 unrolls the
@@ -605,7 +625,11 @@ void filter_strip_kernel(DenoiseArgs a)
     size_t idx_next = 0;
     bool inside_next = false;
     auto issue = [&](int t) {
+#if PTK_DN_ABLATE & 8   // measurement build: every tile reads the first tile's (cached) values
+        const int x0 = 0, y0 = a.row_begin;
+#else
         const int x0 = (t % sc.nbx) * TW, y0 = a.row_begin + (t / sc.nbx) * TH;
+#endif
         const int x = x0 + lx, y = y0 + ly;
         inside_next = x < W && y < a.row_end;
         idx_next = inside_next ? (size_t)y * W + x : 0;
@@ -652,7 +676,14 @@ void filter_strip_kernel(DenoiseArgs a)
 
         if (inside) {
             float wsum[3], wc;
+#if PTK_DN_ABLATE & 4   // measurement build: no taps
+            wsum[0] = ftile[(ly + N) * SW + lx + N] + sd[0] + sd[5] + var[0] + var[6];
+            wsum[1] = ftile[7 * SS + (ly + N) * SW + lx + N] + sd[1] + sd[2] + sd[3] + var[1] + var[2];
+            wsum[2] = ftile[16 * SS + (ly + N) * SW + lx + N] + sd[4] + var[3] + var[4] + var[5];
+            wc = 1.0f;
+#else
             filter_pixel<N>(ftile, SW, SS, ly, lx, N, sd, var, wsum, wc);
+#endif
             const float inv = 1.0f / wc;
             a.denoised[idx] = wsum[0] * inv;
             a.denoised[P + idx] = wsum[1] * inv;
@@ -661,6 +692,258 @@ void filter_strip_kernel(DenoiseArgs a)
         }
         __syncthreads();   // the tile is overwritten at the top of the next iteration
     }
+}
+
+// ---- filter, N = 1, on a window of rows held in registers.
+//
+// A wave owns a strip of 62 pixel columns and walks down a run of rows.  Lane l holds, for
+// column x0 - 1 + l (clamped to the image), the 16 averaged values and stdDev[0] of three
+// consecutive rows; the left and right neighbours of a value are the same register one lane
+// down or up, read through a DPP wave shift, so the 3x3 window needs no LDS, no barrier and no
+// second copy of the data: lanes 1..62 produce outputs, lanes 0 and 63 only carry the halo
+// columns.  Each step converts the row that has just arrived (sums / sample count, the exact
+// quotient), issues the loads of the row after it, and evaluates the nine taps of the row in
+// the middle while those loads fly.  Waves never wait for one another, so a compute unit
+// keeps (rows in flight) x (waves) x 7.4 KB of loads outstanding all the time.  The taps and
+// their order are those of filter_pixel<1>, operand for operand.
+#ifndef PTK_DN_WAVES_ROWS
+#define PTK_DN_WAVES_ROWS 3
+#endif
+#ifndef PTK_DN_ROWS_PER_WAVE
+#define PTK_DN_ROWS_PER_WAVE 0   // measurement builds: fixed run length instead of the host's choice
+#endif
+constexpr int ROWS_COLS = 62;     // output columns per wave
+
+struct RowsGrid {
+    int rows_per_wave, col_groups, segments;
+};
+
+// Arithmetic whose first operand is taken from the lane below (DX = -1: lane l reads lane
+// l - 1) or above (DX = +1) through the DPP wave shift of the instruction itself, so that a
+// neighbour's value costs no instruction of its own.  Lanes with no such neighbour (lane 0,
+// lane 63) read zero; their results are never used.  The hardware needs two wait states
+// between a vector write of a register and a DPP read of it, and the compiler cannot see
+// inside these statements: the only registers read this way are a row's values, and
+// rows_settle() below stands between their conversion and the taps.
+#define PTK_DPP_BELOW " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define PTK_DPP_ABOVE " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+DEV void rows_settle()
+{
+    __builtin_amdgcn_sched_barrier(0);   // nothing is moved across: conversions above, taps below
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int DX>
+DEV float shifted_sub(float q, float p)     // q(lane + DX) - p
+{
+    float d;
+    if (DX < 0) asm("v_sub_f32_dpp %0, %1, %2" PTK_DPP_BELOW : "=v"(d) : "v"(q), "v"(p));
+    else asm("v_sub_f32_dpp %0, %1, %2" PTK_DPP_ABOVE : "=v"(d) : "v"(q), "v"(p));
+    return d;
+}
+template <int DX>
+DEV float shifted_add(float q, float p)     // q(lane + DX) + p
+{
+    float d;
+    if (DX < 0) asm("v_add_f32_dpp %0, %1, %2" PTK_DPP_BELOW : "=v"(d) : "v"(q), "v"(p));
+    else asm("v_add_f32_dpp %0, %1, %2" PTK_DPP_ABOVE : "=v"(d) : "v"(q), "v"(p));
+    return d;
+}
+// acc[i] = fma(q[i](lane + DX), w, acc[i]), i = 0..2.  w comes straight from v_exp_f32, and a
+// transcendental result needs a wait state before an ordinary vector instruction reads it
+// (inserted by the compiler for its own instructions only).
+template <int DX>
+DEV void shifted_fmac3(float (&acc)[3], const float (&q)[16], float w)
+{
+    if (DX < 0)
+        asm("s_nop 1\n\tv_fmac_f32_dpp %0, %3, %6" PTK_DPP_BELOW "\n\tv_fmac_f32_dpp %1, %4, %6" PTK_DPP_BELOW
+            "\n\tv_fmac_f32_dpp %2, %5, %6" PTK_DPP_BELOW
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(w));
+    else
+        asm("s_nop 1\n\tv_fmac_f32_dpp %0, %3, %6" PTK_DPP_ABOVE "\n\tv_fmac_f32_dpp %1, %4, %6" PTK_DPP_ABOVE
+            "\n\tv_fmac_f32_dpp %2, %5, %6" PTK_DPP_ABOVE
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(w));
+}
+
+struct RowRegs {
+    float q[16];
+    float sd0;
+};
+struct RawRow {
+    float v[FV];
+};
+struct CentreRegs {   // stdDev[1..5] and the seven bandwidths of the pixel being filtered
+    float sd[5], var[7];
+};
+
+// Loads of one image row: every address is a wave-uniform row base (scalar registers) plus
+// the lane's byte offset in the row, which never changes, so the 29 streams of a wave cost one
+// address register between them.  The row base is pinned to scalar registers: otherwise the
+// compiler folds the lane offset into it and carries one 64-bit vector address per stream
+// through the row loop.
+typedef __attribute__((address_space(1))) char GlobalByte;
+DEV GlobalByte* rows_base(const void* plane0, int W, int H, int y)
+{
+    // the clamp compiles to a vector min/max; back to a scalar register before the multiply
+    const int yc = __builtin_amdgcn_readfirstlane(clampi(y, H));
+    const unsigned long long v =
+        (unsigned long long)plane0 + (unsigned long long)yc * (unsigned long long)W * sizeof(float);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (GlobalByte*)(((unsigned long long)hi << 32) | lo);
+}
+DEV float rows_load(GlobalByte* row, size_t plane_bytes, int k, unsigned lane_bytes)
+{
+    GlobalByte* plane_row = row + (size_t)k * plane_bytes;
+    asm("" : "+s"(plane_row));   // stays in scalar registers: the lane offset is not folded in
+    return *(const __attribute__((address_space(1))) float*)(plane_row + lane_bytes);
+}
+DEV void rows_store(GlobalByte* row, unsigned lane_bytes, float v)
+{
+    asm("" : "+s"(row));
+    *(__attribute__((address_space(1))) float*)(row + lane_bytes) = v;
+}
+DEV void rows_issue(const DenoiseArgs& a, size_t PB, unsigned lane_bytes, int y, RawRow& raw)
+{
+    GlobalByte* row = rows_base(a.planes, a.width, a.height, y);
+#pragma unroll
+    for (int k = 0; k < 16; k++) raw.v[k] = rows_load(row, PB, k, lane_bytes);
+    raw.v[16] = rows_load(row, PB, PTK_PL_SD, lane_bytes);
+}
+DEV void rows_issue_centre(const DenoiseArgs& a, size_t PB, unsigned lane_bytes, int y, CentreRegs& c)
+{
+    GlobalByte* row = rows_base(a.planes, a.width, a.height, y);
+    GlobalByte* vrow = rows_base(a.variances, a.width, a.height, y);
+#pragma unroll
+    for (int k = 0; k < 5; k++) c.sd[k] = rows_load(row, PB, PTK_PL_SD + 1 + k, lane_bytes);
+#pragma unroll
+    for (int k = 0; k < 7; k++) c.var[k] = rows_load(vrow, PB, k, lane_bytes);
+}
+DEV void rows_convert(const RawRow& raw, const Recip& dv, RowRegs& r)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) r.q[k] = div_by(raw.v[k], dv);
+    r.sd0 = raw.v[16];
+}
+
+// The neighbour DX lanes away in row r.
+template <int DX>
+struct NeighbourLane {
+    const RowRegs& r;
+    const float (&pv)[16];
+    DEV float diff(int k) const { return DX == 0 ? r.q[k] - pv[k] : shifted_sub<DX>(r.q[k], pv[k]); }
+    DEV float sd0_sum(float s) const { return DX == 0 ? s + r.sd0 : shifted_add<DX>(r.sd0, s); }
+    DEV void accumulate(float w, float (&wsum)[3]) const
+    {
+        if (DX == 0) {
+            wsum[0] += r.q[0] * w;
+            wsum[1] += r.q[1] * w;
+            wsum[2] += r.q[2] * w;
+        } else {
+            shifted_fmac3<DX>(wsum, r.q, w);
+        }
+    }
+};
+template <int DX>
+DEV void rows_tap(const RowRegs& r, float dist_idx, const float (&pv)[16], const FilterCoef& c,
+                  float (&wsum)[3], float& wc)
+{
+    filter_tap_core(NeighbourLane<DX>{r, pv}, dist_idx, c, wsum, wc);
+}
+
+// One row of outputs: `up`, `mid`, `down` are rows y-1, y, y+1.
+DEV void rows_output(const DenoiseArgs& a, size_t PB, const RowRegs& up, const RowRegs& mid,
+                     const RowRegs& down, const CentreRegs& cr, bool store, int y,
+                     unsigned lane_bytes)
+{
+    float sd[6], wsum[3] = {0.0f, 0.0f, 0.0f}, wc = 0.0f;
+    sd[0] = mid.sd0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) sd[1 + k] = cr.sd[k];
+    const FilterCoef c = make_coef(sd, cr.var);
+#if PTK_DN_ABLATE & 4   // measurement build: no taps
+    wsum[0] = up.q[0] + up.q[5] + up.q[9] + up.q[15] + c.inv_idx + c.inv_nrm + c.inv_a1 + up.q[1] + up.q[6] + up.q[10] + up.sd0;
+    wsum[1] = mid.q[1] + mid.q[4] + mid.q[8] + mid.q[14] + c.inv_a2 + c.inv_wp + c.inv_dl + up.q[2] + up.q[7] + up.q[11];
+    wsum[2] = down.q[2] + down.q[3] + down.q[7] + down.q[13] + c.col_scale + c.sd0 + up.q[3] + up.q[8] + up.q[12] + up.q[4] + up.q[13] + up.q[14];
+    wc = 1.0f;
+#elif PTK_DN_ABLATE & 16   // measurement build: three taps of nine
+    rows_tap<-1>(up, 2.0f, mid.q, c, wsum, wc);
+    rows_tap<0>(mid, 0.0f, mid.q, c, wsum, wc);
+    rows_tap<1>(down, 2.0f, mid.q, c, wsum, wc);
+#else
+    rows_tap<-1>(up, 2.0f, mid.q, c, wsum, wc);
+    rows_tap<0>(up, 1.0f, mid.q, c, wsum, wc);
+    rows_tap<1>(up, 2.0f, mid.q, c, wsum, wc);
+    rows_tap<-1>(mid, 1.0f, mid.q, c, wsum, wc);
+    rows_tap<0>(mid, 0.0f, mid.q, c, wsum, wc);
+    rows_tap<1>(mid, 1.0f, mid.q, c, wsum, wc);
+    rows_tap<-1>(down, 2.0f, mid.q, c, wsum, wc);
+    rows_tap<0>(down, 1.0f, mid.q, c, wsum, wc);
+    rows_tap<1>(down, 2.0f, mid.q, c, wsum, wc);
+#endif
+    if (store) {
+        const float inv = 1.0f / wc;
+        GlobalByte* out = rows_base(a.denoised, a.width, a.height, y);
+        GlobalByte* wout = rows_base(a.wc_sum, a.width, a.height, y);
+        rows_store(out, lane_bytes, wsum[0] * inv);
+        rows_store(out + PB, lane_bytes, wsum[1] * inv);
+        rows_store(out + 2 * PB, lane_bytes, wsum[2] * inv);
+        rows_store(wout, lane_bytes, wc);
+    }
+}
+
+__global__ __launch_bounds__(256, PTK_DN_WAVES_ROWS) void filter_rows_kernel(DenoiseArgs a, RowsGrid g)
+{
+    const int W = a.width;
+    const size_t PB = (size_t)W * a.height * sizeof(float);   // bytes per plane
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: rows and strips are wave-uniform
+    // workgroup -> (row segment, group of four strips); each XCD takes a contiguous run
+    const int nwg = g.col_groups * g.segments, per = (nwg + 7) >> 3;
+    const int wg = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || wg >= nwg) return;
+    const int seg = wg / g.col_groups, x0 = ((wg - seg * g.col_groups) * 4 + wave) * ROWS_COLS;
+    if (x0 >= W) return;
+    const int y_begin = a.row_begin + seg * g.rows_per_wave;
+    const int y_end = min(y_begin + g.rows_per_wave, a.row_end);
+    const int xl = x0 - 1 + lane;
+    const unsigned gx = (unsigned)clampi(xl, W) * (unsigned)sizeof(float);   // byte offset in a row
+    const bool writer = lane >= 1 && lane <= ROWS_COLS && xl < W;
+    const Recip dv = make_recip((float)a.sample_count);
+
+    RowRegs r0, r1, r2;
+    RawRow raw;
+    CentreRegs cnext;
+    {
+        RawRow first;
+        rows_issue(a, PB, gx, y_begin - 1, first);
+        rows_issue(a, PB, gx, y_begin, raw);
+        rows_convert(first, dv, r0);
+        rows_convert(raw, dv, r1);
+        rows_settle();
+    }
+    rows_issue(a, PB, gx, y_begin + 1, raw);
+    rows_issue_centre(a, PB, gx, y_begin, cnext);
+
+    // step: rows (up, mid) are converted, `raw` holds row y + 1 and cnext the centre values
+    // of row y, both in flight
+#define PTK_ROWS_STEP(up, mid, down, y)                                                  \
+    {                                                                                      \
+        rows_convert(raw, dv, down);                                                       \
+        rows_settle();                                                                     \
+        const CentreRegs cr = cnext;                                                       \
+        rows_issue(a, PB, gx, (y) + 2, raw);                                                \
+        rows_issue_centre(a, PB, gx, (y) + 1, cnext);                                       \
+        rows_output(a, PB, up, mid, down, cr, writer, (y), gx);                \
+    }
+    for (int y = y_begin; y < y_end; y += 3) {
+        PTK_ROWS_STEP(r0, r1, r2, y)
+        if (y + 1 >= y_end) break;
+        PTK_ROWS_STEP(r1, r2, r0, y + 1)
+        if (y + 2 >= y_end) break;
+        PTK_ROWS_STEP(r2, r0, r1, y + 2)
+    }
+#undef PTK_ROWS_STEP
 }
 
 size_t filter_lds_bytes(int N)
@@ -691,9 +974,8 @@ hipError_t launch_dyn(K kernel, const DenoiseArgs& a, size_t lds, hipStream_t st
 
 }  // namespace
 
-// Grid of a strip kernel: `per_cu` workgroups for each of the device's compute
-// units (a multiple of eight, one share per XCD), never more than one per tile.
-unsigned strip_grid(const DenoiseArgs& a, int per_cu)
+// Compute units of the current device (0 on failure).
+static int device_cus()
 {
     static int cus = 0;
     if (cus == 0) {
@@ -703,6 +985,15 @@ unsigned strip_grid(const DenoiseArgs& a, int per_cu)
             return 0;
         cus = prop.multiProcessorCount;
     }
+    return cus;
+}
+
+// Grid of a strip kernel: `per_cu` workgroups for each of the device's compute
+// units (a multiple of eight, one share per XCD), never more than one per tile.
+unsigned strip_grid(const DenoiseArgs& a, int per_cu)
+{
+    const int cus = device_cus();
+    if (cus == 0) return 0;
     const unsigned tiles = (unsigned)((a.width + TW - 1) / TW) *
                            (unsigned)((a.row_end - a.row_begin + TH - 1) / TH);
     unsigned groups = (unsigned)cus * (unsigned)per_cu;
@@ -739,9 +1030,39 @@ hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// Run length of the register-window kernel: as many waves as the device holds at once (or
+// a whole multiple of that), so that every wave slot streams for the whole launch.
+hipError_t launch_rows(const DenoiseArgs& a, hipStream_t stream)
+{
+    const int cus = device_cus();
+    if (cus == 0) return hipErrorInvalidDevice;
+    const int rows = a.row_end - a.row_begin;
+    RowsGrid g;
+    const int strips = (a.width + ROWS_COLS - 1) / ROWS_COLS;
+    g.col_groups = (strips + 3) / 4;
+    const int slots = cus * PTK_DN_WAVES_ROWS;          // workgroups resident at once
+    int segs = slots / g.col_groups;
+    if (segs < 1) segs = 1;
+    g.rows_per_wave = (rows + segs - 1) / segs;
+    if (g.rows_per_wave < 8) g.rows_per_wave = rows < 8 ? rows : 8;
+#if PTK_DN_ROWS_PER_WAVE
+    g.rows_per_wave = PTK_DN_ROWS_PER_WAVE;
+#endif
+    g.segments = (rows + g.rows_per_wave - 1) / g.rows_per_wave;
+    const unsigned nwg = (unsigned)(g.col_groups * g.segments);
+    hipLaunchKernelGGL(filter_rows_kernel, dim3((nwg + 7u) / 8u * 8u), dim3(256), 0, stream, a, g);
+    return hipGetLastError();
+}
+
+#ifndef PTK_DN_ROWS
+#define PTK_DN_ROWS 1
+#endif
 hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
 {
     size_t lds = filter_lds_bytes(a.n);
+#if PTK_DN_ROWS
+    if (a.n == 1) return launch_rows(a, stream);
+#endif
 #if PTK_DN_STRIP
     if (a.n == 1) return launch_strip(filter_strip_kernel<1>, a, lds, PTK_DN_STRIP_PER_CU, stream);
     if (a.n == 2) return launch_strip(filter_strip_kernel<2>, a, lds, 2, stream);
