@@ -473,24 +473,27 @@ DEV FilterCoef make_coef(const float* sd, const float* var)
 // One filter tap (Denoiser.cpp:301-348): the product of the seven Gaussians is one exp of
 // the summed exponents.  `nb` supplies the neighbour: diff(k) = its value k minus the centre
 // pixel's, sd0_sum(s) = s + its stdDev[0], accumulate(w, wsum) adds its colour times w.
+// Every fused multiply-add is written out, so that each kernel built on this function forms
+// the same roundings whatever its surrounding code.
 template <class Neighbour>
 DEV void filter_tap_core(const Neighbour& nb, float dist_idx, const FilterCoef& c,
                          float (&wsum)[3], float& wc)
 {
+#pragma clang fp contract(off)
     float d2[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         float dx = nb.diff(3 * k), dy = nb.diff(3 * k + 1), dz = nb.diff(3 * k + 2);
-        d2[k] = dx * dx + dy * dy + dz * dz;
+        d2[k] = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
     }
     float ddl = nb.diff(15);
     float arg = dist_idx * c.inv_idx;
-    arg += d2[0] * fast_rcp(nb.sd0_sum(c.sd0) * c.col_scale + 0.000001f);
-    arg += d2[1] * c.inv_nrm;
-    arg += d2[2] * c.inv_a1;
-    arg += d2[3] * c.inv_a2;
-    arg += d2[4] * c.inv_wp;
-    arg += ddl * ddl * c.inv_dl;
+    arg = __builtin_fmaf(d2[0], fast_rcp(__builtin_fmaf(nb.sd0_sum(c.sd0), c.col_scale, 0.000001f)), arg);
+    arg = __builtin_fmaf(d2[1], c.inv_nrm, arg);
+    arg = __builtin_fmaf(d2[2], c.inv_a1, arg);
+    arg = __builtin_fmaf(d2[3], c.inv_a2, arg);
+    arg = __builtin_fmaf(d2[4], c.inv_wp, arg);
+    arg = __builtin_fmaf(ddl * ddl, c.inv_dl, arg);
     float w = fast_exp(-arg);
     nb.accumulate(w, wsum);
     wc += w;
@@ -505,9 +508,9 @@ struct NeighbourValues {
     DEV float sd0_sum(float s) const { return s + sd0q; }
     DEV void accumulate(float w, float (&wsum)[3]) const
     {
-        wsum[0] += q[0] * w;
-        wsum[1] += q[1] * w;
-        wsum[2] += q[2] * w;
+        wsum[0] = __builtin_fmaf(q[0], w, wsum[0]);
+        wsum[1] = __builtin_fmaf(q[1], w, wsum[1]);
+        wsum[2] = __builtin_fmaf(q[2], w, wsum[2]);
     }
 };
 
@@ -715,7 +718,7 @@ void filter_strip_kernel(DenoiseArgs a)
 constexpr int ROWS_COLS = 62;     // output columns per wave
 
 struct RowsGrid {
-    int rows_per_wave, col_groups, segments;
+    int col_groups, segments;
 };
 
 // Arithmetic whose first operand is taken from the lane below (DX = -1: lane l reads lane
@@ -836,9 +839,9 @@ struct NeighbourLane {
     DEV void accumulate(float w, float (&wsum)[3]) const
     {
         if (DX == 0) {
-            wsum[0] += r.q[0] * w;
-            wsum[1] += r.q[1] * w;
-            wsum[2] += r.q[2] * w;
+            wsum[0] = __builtin_fmaf(r.q[0], w, wsum[0]);
+            wsum[1] = __builtin_fmaf(r.q[1], w, wsum[1]);
+            wsum[2] = __builtin_fmaf(r.q[2], w, wsum[2]);
         } else {
             shifted_fmac3<DX>(wsum, r.q, w);
         }
@@ -892,6 +895,48 @@ DEV void rows_output(const DenoiseArgs& a, size_t PB, const RowRegs& up, const R
     }
 }
 
+// `count` rows starting at row y0 and moving by DIR (+1 down the image, -1 up).  r0, r1, r2
+// rotate through the roles (row behind, row being filtered, row ahead).
+template <int DIR>
+DEV void rows_walk(const DenoiseArgs& a, size_t PB, unsigned gx, bool writer, const Recip& dv, int y0,
+                   int count)
+{
+    RowRegs r0, r1, r2;
+    RawRow raw;
+    CentreRegs cnext;
+    {
+        RawRow first;
+        rows_issue(a, PB, gx, y0 - DIR, first);
+        rows_issue(a, PB, gx, y0, raw);
+        rows_convert(first, dv, r0);
+        rows_convert(raw, dv, r1);
+        rows_settle();
+    }
+    rows_issue(a, PB, gx, y0 + DIR, raw);
+    rows_issue_centre(a, PB, gx, y0, cnext);
+
+    // step: rows (behind, mid) are converted, `raw` holds the row ahead and cnext the centre
+    // values of row y, both in flight; the taps always run from the row above to the row below
+#define PTK_ROWS_STEP(behind, mid, ahead, y)                                               \
+    {                                                                                      \
+        rows_convert(raw, dv, ahead);                                                      \
+        rows_settle();                                                                     \
+        const CentreRegs cr = cnext;                                                       \
+        rows_issue(a, PB, gx, (y) + 2 * DIR, raw);                                         \
+        rows_issue_centre(a, PB, gx, (y) + DIR, cnext);                                    \
+        if (DIR > 0) rows_output(a, PB, behind, mid, ahead, cr, writer, (y), gx);          \
+        else rows_output(a, PB, ahead, mid, behind, cr, writer, (y), gx);                  \
+    }
+    for (int i = 0, y = y0; i < count; i += 3, y += 3 * DIR) {
+        PTK_ROWS_STEP(r0, r1, r2, y)
+        if (i + 1 >= count) break;
+        PTK_ROWS_STEP(r1, r2, r0, y + DIR)
+        if (i + 2 >= count) break;
+        PTK_ROWS_STEP(r2, r0, r1, y + 2 * DIR)
+    }
+#undef PTK_ROWS_STEP
+}
+
 __global__ __launch_bounds__(256, PTK_DN_WAVES_ROWS) void filter_rows_kernel(DenoiseArgs a, RowsGrid g)
 {
     const int W = a.width;
@@ -904,46 +949,22 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES_ROWS) void filter_rows_kernel(Den
     if ((int)(blockIdx.x >> 3) >= per || wg >= nwg) return;
     const int seg = wg / g.col_groups, x0 = ((wg - seg * g.col_groups) * 4 + wave) * ROWS_COLS;
     if (x0 >= W) return;
-    const int y_begin = a.row_begin + seg * g.rows_per_wave;
-    const int y_end = min(y_begin + g.rows_per_wave, a.row_end);
+    // the band's rows are dealt to the segments as evenly as integers allow
+    const int rows = a.row_end - a.row_begin;
+    const int y_begin = a.row_begin + (int)((long long)seg * rows / g.segments);
+    const int y_end = a.row_begin + (int)((long long)(seg + 1) * rows / g.segments);
     const int xl = x0 - 1 + lane;
     const unsigned gx = (unsigned)clampi(xl, W) * (unsigned)sizeof(float);   // byte offset in a row
     const bool writer = lane >= 1 && lane <= ROWS_COLS && xl < W;
     const Recip dv = make_recip((float)a.sample_count);
 
-    RowRegs r0, r1, r2;
-    RawRow raw;
-    CentreRegs cnext;
-    {
-        RawRow first;
-        rows_issue(a, PB, gx, y_begin - 1, first);
-        rows_issue(a, PB, gx, y_begin, raw);
-        rows_convert(first, dv, r0);
-        rows_convert(raw, dv, r1);
-        rows_settle();
-    }
-    rows_issue(a, PB, gx, y_begin + 1, raw);
-    rows_issue_centre(a, PB, gx, y_begin, cnext);
-
-    // step: rows (up, mid) are converted, `raw` holds row y + 1 and cnext the centre values
-    // of row y, both in flight
-#define PTK_ROWS_STEP(up, mid, down, y)                                                  \
-    {                                                                                      \
-        rows_convert(raw, dv, down);                                                       \
-        rows_settle();                                                                     \
-        const CentreRegs cr = cnext;                                                       \
-        rows_issue(a, PB, gx, (y) + 2, raw);                                                \
-        rows_issue_centre(a, PB, gx, (y) + 1, cnext);                                       \
-        rows_output(a, PB, up, mid, down, cr, writer, (y), gx);                \
-    }
-    for (int y = y_begin; y < y_end; y += 3) {
-        PTK_ROWS_STEP(r0, r1, r2, y)
-        if (y + 1 >= y_end) break;
-        PTK_ROWS_STEP(r1, r2, r0, y + 1)
-        if (y + 2 >= y_end) break;
-        PTK_ROWS_STEP(r2, r0, r1, y + 2)
-    }
-#undef PTK_ROWS_STEP
+    // Even segments walk down, odd ones up: a segment and its neighbour then start at
+    // adjacent rows and meet at adjacent rows, so the halo row each reads from the other is
+    // in the XCD's L2 when it is wanted instead of being fetched from HBM a second time.
+    if (seg & 1)
+        rows_walk<-1>(a, PB, gx, writer, dv, y_end - 1, y_end - y_begin);
+    else
+        rows_walk<1>(a, PB, gx, writer, dv, y_begin, y_end - y_begin);
 }
 
 size_t filter_lds_bytes(int N)
@@ -1041,14 +1062,13 @@ hipError_t launch_rows(const DenoiseArgs& a, hipStream_t stream)
     const int strips = (a.width + ROWS_COLS - 1) / ROWS_COLS;
     g.col_groups = (strips + 3) / 4;
     const int slots = cus * PTK_DN_WAVES_ROWS;          // workgroups resident at once
-    int segs = slots / g.col_groups;
-    if (segs < 1) segs = 1;
-    g.rows_per_wave = (rows + segs - 1) / segs;
-    if (g.rows_per_wave < 8) g.rows_per_wave = rows < 8 ? rows : 8;
+    int segs = slots / g.col_groups;                    // one resident round
 #if PTK_DN_ROWS_PER_WAVE
-    g.rows_per_wave = PTK_DN_ROWS_PER_WAVE;
+    segs = (rows + PTK_DN_ROWS_PER_WAVE - 1) / PTK_DN_ROWS_PER_WAVE;
 #endif
-    g.segments = (rows + g.rows_per_wave - 1) / g.rows_per_wave;
+    if (segs > rows / 8) segs = rows / 8;               // runs of at least eight rows
+    if (segs < 1) segs = 1;
+    g.segments = segs;
     const unsigned nwg = (unsigned)(g.col_groups * g.segments);
     hipLaunchKernelGGL(filter_rows_kernel, dim3((nwg + 7u) / 8u * 8u), dim3(256), 0, stream, a, g);
     return hipGetLastError();
