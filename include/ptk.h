@@ -268,9 +268,11 @@ int ptk_auto_exposure_static(const float* colour_planes_d, size_t pixels, int wi
  * neighbourhood features -> 36-10-10-7 MLP (weights in the file order of
  * DenoiserNN.cpp:1625-1663: w12[36*node+input], w23[10*node+input],
  * w34[10*node+input]) -> (2N+1)^2 clamp-to-edge cross-bilateral filter.
- * variant must be 0 (a feature + MLP kernel, then a filter kernel; the argument
- * is kept for binary compatibility: a single fused kernel was measured slower
- * than the two launches and removed, and 1 is PTK_ERR_ARG).
+ * variant 0 is the denoiser (a feature + MLP kernel, then a filter kernel: for
+ * N = 1 on a register window of rows, for wider windows on LDS tiles).  variant 1
+ * forces the LDS-tile filter at N = 1 too: same arithmetic, same bits, slower; it
+ * exists so that the two forms can be checked against each other.  Anything else
+ * is PTK_ERR_ARG.
  * Outputs (all optional): denoised rgb interleaved (3P), wcSum (P),
  * variances (7P, pixel-major), features (36P, pixel-major). */
 int ptk_denoise(ptk_ctx* ctx, const float w12[360], const float w23[100], const float w34[70],

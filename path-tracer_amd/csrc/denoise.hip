@@ -1077,11 +1077,11 @@ hipError_t launch_rows(const DenoiseArgs& a, hipStream_t stream)
 #ifndef PTK_DN_ROWS
 #define PTK_DN_ROWS 1
 #endif
-hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream)
+hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream, bool lds_tiles)
 {
     size_t lds = filter_lds_bytes(a.n);
 #if PTK_DN_ROWS
-    if (a.n == 1) return launch_rows(a, stream);
+    if (a.n == 1 && !lds_tiles) return launch_rows(a, stream);
 #endif
 #if PTK_DN_STRIP
     if (a.n == 1) return launch_strip(filter_strip_kernel<1>, a, lds, PTK_DN_STRIP_PER_CU, stream);

@@ -201,4 +201,6 @@ hipError_t ptk_launch_train(const TrainArgs& a, hipStream_t stream);
 // target = colour sums / sample count (Denoiser::saveTargetCol, Denoiser.cpp:148-155)
 hipError_t ptk_launch_save_target(const float* planes, float* target, size_t pixels,
                                   int sample_count, hipStream_t stream);
-hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream);
+// lds_tiles: N = 1 also takes the LDS-tile kernel that serves the wider windows (same
+// arithmetic, kept callable so the two forms can be compared bit for bit).
+hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream, bool lds_tiles = false);

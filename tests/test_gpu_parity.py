@@ -184,7 +184,51 @@ def test_denoiser_odd_sizes_and_edges(ctx, oracle):
         assert _rel_ok(r["wcSum"], wc, 5e-5).all()
     import ptk
     with pytest.raises(ptk.PtkError, match="variant"):
-        ctx.denoise(w, 1, 1)            # the fused single-kernel variant no longer exists
+        ctx.denoise(w, 1, 2)            # only variants 0 and 1 exist
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(37, 23), (61, 3), (62, 8), (63, 9), (64, 17), (253, 131), (1920, 1080)])
+def test_filter_row_window_kernel_equals_the_tile_kernel_bit_for_bit(ctx, oracle, size):
+    """N = 1 runs on a register window of rows (62-column strips, walked down or up the
+    image, neighbours through DPP operands); variant 1 forces the LDS-tile kernel the wider
+    windows use.  Both evaluate the same taps in the same order with the same roundings, so
+    every output word must be identical: whole image and ragged row bands, at widths around
+    the strip and wave sizes and at full size."""
+    O = oracle
+    W, H = size
+    rng = np.random.default_rng(W * 1000 + H)
+    P = W * H
+    spp = 7                                             # not a power of two: exact quotients
+    pl = np.zeros((38, P), np.float32)
+    pl[0:16] = (rng.uniform(-1, 1, (16, P)) * spp).astype(np.float32)
+    pl[15] = rng.choice([0, .25, .5, .75, 1.0], P) * spp
+    pl[32:38] = rng.uniform(1e-4, 0.5, (6, P))
+    sc = O.load_scene(scene_path("cornell_crystal"))
+    ctx.set_constants(O.build_constants(sc, W, H, 4, 0.005, True))
+    ctx.write_planes(pl, spp)
+    w = O.load_weights(weights_path("box_grid"))
+    a = ctx.denoise(w, 1, 0)
+    b = ctx.denoise(w, 1, 1)
+    for k in ("denoised", "wcSum", "variances"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    if H >= 9:                                          # a band that starts and ends mid-image
+        import torch
+        import multigpu
+        den, wc = multigpu.device_denoised(ctx, torch.device("cuda", 0))
+        def band(variant, y0, y1):
+            den.zero_()
+            wc.zero_()
+            torch.cuda.synchronize()
+            ctx.denoise_rows(w, 1, variant, y0, y1)
+            ctx.synchronize()
+            return np.concatenate([den.cpu().numpy().reshape(3, P), wc.cpu().numpy().reshape(1, P)])
+        y0, y1 = 2, H - 3
+        b0, b1 = band(0, y0, y1), band(1, y0, y1)
+        assert np.array_equal(b0.view(np.uint32), b1.view(np.uint32))
+        assert not b0[:, :y0 * W].any() and not b0[:, y1 * W:].any()    # nothing outside the band
+        full = np.concatenate([a["denoised"].T, a["wcSum"].reshape(1, P)])
+        assert np.array_equal(b0[:, y0 * W:y1 * W].view(np.uint32), full[:, y0 * W:y1 * W].view(np.uint32))
 
 
 def test_render_odd_sizes_depths_and_empty_scene(ctx, oracle):
