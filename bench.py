@@ -35,7 +35,7 @@ import ptk  # noqa: E402
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector fp32 peak (FMA = 2 flop)
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
 PEAK_VALU_ISSUE_T = 78.6   # lane-instructions/s: 256 CUs x 4 SIMDs x 32 lanes/cycle x 2.4 GHz
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r01_profile_summary.json")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02_profile_summary.json")
 
 
 def load_opcount(scene):
@@ -432,7 +432,7 @@ def main():
                                                   + prof["hbm_write_bytes_per_launch"])
                     out["roofline"]["traffic_note"] = (
                         "rocprofv3 FETCH_SIZE (x calibration) + WRITE_SIZE per launch from "
-                        "profiles/r01_profile_summary.json: register-spill scratch traffic, "
+                        "profiles/r02_profile_summary.json: register-spill scratch traffic, "
                         "not plane traffic")
                 if "SQ_INSTS_VALU" in pmc:
                     lane_instr = pmc["SQ_INSTS_VALU"] * 64.0

@@ -388,6 +388,9 @@ DEV bool tile_origin(const DenoiseArgs& a, int& x0, int& y0)
     return true;
 }
 
+// KEEP: the 36 features and / or the two hidden layers are written out as well (a caller's
+// request, or the training step); the inference launch carries no such stores.
+template <bool KEEP>
 __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(DenoiseArgs a)
 {
     __shared__ float tile[PTILE_FLOATS + PTK_DN_LDS_PAD];
@@ -411,7 +414,8 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
 
     float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, a.features, a.layers, P, idx, var);
+    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, KEEP ? a.features : nullptr,
+                     KEEP ? a.layers : nullptr, P, idx, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
 }
@@ -1047,7 +1051,10 @@ hipError_t launch_strip(K kernel, const DenoiseArgs& a, size_t lds, int per_cu, 
 hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
 {
     dim3 grid(denoise_grid(a));
-    hipLaunchKernelGGL(features_mlp_kernel, grid, dim3(256), 0, stream, a);
+    if (a.features || a.layers)
+        hipLaunchKernelGGL(features_mlp_kernel<true>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(features_mlp_kernel<false>, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
