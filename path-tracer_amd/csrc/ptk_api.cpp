@@ -38,7 +38,8 @@ int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                             \
     } while (0)
 
-// Seed passes are uploaded in chunks of at most this many bytes.
+// Seed passes are uploaded in chunks of at most this many bytes, and of one whole pass at
+// least (16 bytes per pixel: 133 MB at 4K, 531 MB at 8K).
 constexpr size_t SEED_CHUNK_BYTES = size_t(256) << 20;
 
 }  // namespace
@@ -887,8 +888,17 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
             if (c->seeds_h) (void)hipHostFree(c->seeds_h);
             c->seeds_h = nullptr;
             c->seed_capacity = 0;
-            HIP_TRY(hipMalloc((void**)&c->seeds_d, want * per_pass));
-            HIP_TRY(hipHostMalloc((void**)&c->seeds_h, want * per_pass, hipHostMallocDefault));
+            // one whole pass at least: 16 bytes per pixel, device and pinned host
+            hipError_t ea = hipMalloc((void**)&c->seeds_d, want * per_pass);
+            if (ea == hipSuccess)
+                ea = hipHostMalloc((void**)&c->seeds_h, want * per_pass, hipHostMallocDefault);
+            if (ea != hipSuccess) {
+                (void)hipFree(c->seeds_d); c->seeds_d = nullptr;
+                (void)hipGetLastError();
+                return fail(ea == hipErrorOutOfMemory ? PTK_ERR_NOMEM : PTK_ERR_HIP,
+                            "ptk_render: %zu bytes of seed staging (reference seeds take 16 bytes "
+                            "per pixel per pass): %s", want * per_pass, hipGetErrorString(ea));
+            }
             c->seed_capacity = want;
         }
         uint64_t g0 = glo_seed[0], g1 = glo_seed[1];
