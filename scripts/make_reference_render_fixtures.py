@@ -1,0 +1,16 @@
+"""Re-encodes the reference's checked-in noisy renders of MultiLightGlass (ASCII PPM) as
+compressed arrays under tests/golden/reference_renders/.  Run where /root/reference exists."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/Renders"
+DST = os.path.join(ROOT, "tests", "golden", "reference_renders")
+os.makedirs(DST, exist_ok=True)
+for spp in (5000, 2500, 128):
+    name = "MultLightGlass-0.4-%d-N" % spp
+    t = open(os.path.join(SRC, name + ".ppm")).read().split()
+    assert t[0] == "P3" and t[3] == "255"
+    W, H = int(t[1]), int(t[2])
+    rgb = np.array(t[4:], dtype=np.uint16).reshape(H, W, 3)
+    np.savez_compressed(os.path.join(DST, name + ".npz"), rgb=rgb)
+    print(name, rgb.shape, rgb.max())
