@@ -11,7 +11,9 @@ __global__ __launch_bounds__(256) void probe(float* out, float b, float c)
 {
     f2 a[8];
     float s[8];
-    for (int i = 0; i < 8; i++) { a[i] = {threadIdx.x * 1e-3f + i, threadIdx.x * 2e-3f + i}; s[i] = threadIdx.x * 1e-3f + i; }
+    double dd[8];
+    const double db = b, dc = c;
+    for (int i = 0; i < 8; i++) { a[i] = {threadIdx.x * 1e-3f + i, threadIdx.x * 2e-3f + i}; s[i] = threadIdx.x * 1e-3f + i; dd[i] = threadIdx.x * 1e-3 + i; }
     const f2 bb = {b, b * 1.0001f}, cc = {c, c * 1.5f};
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
@@ -38,10 +40,20 @@ __global__ __launch_bounds__(256) void probe(float* out, float b, float c)
             if (KIND == 19) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s[i]) : "s"(b), "v"(c));
             if (KIND == 20) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(s[i]));
             if (KIND == 21) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(s[i]) : "v"(c));
+            if (KIND == 22) asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(dd[i]) : "v"(s[i]));
+            if (KIND == 23) asm volatile("v_cvt_f32_f64_e32 %0, %1" : "=v"(s[i]) : "v"(dd[i]));
+            if (KIND == 24) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(db));
+            if (KIND == 25) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(dd[i]) : "v"(db), "v"(dc));
+            if (KIND == 26) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(s[i]) : "v"(b), "v"(c));
+            if (KIND == 27) asm volatile("v_rcp_f32_e32 %0, %0" : "+v"(s[i]));
+            if (KIND == 28) asm volatile("v_sqrt_f32_e32 %0, %0" : "+v"(s[i]));
+            if (KIND == 29) asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[i]));
+            if (KIND == 30) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(s[i]) : "v"(b), "v"(c));
+            if (KIND == 31) asm volatile("v_add_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dc));
         }
     }
     float r = 0;
-    for (int i = 0; i < 8; i++) r += a[i].x + a[i].y + s[i];
+    for (int i = 0; i < 8; i++) r += a[i].x + a[i].y + s[i] + (float)dd[i];
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 template <int KIND>
@@ -90,4 +102,14 @@ int main()
     run<19>("v_fma_f32 sgpr src", 1);
     run<20>("v_lshlrev_b32", 1);
     run<21>("v_mov_b32", 1);
+    run<22>("v_cvt_f64_f32", 1);
+    run<23>("v_cvt_f32_f64", 1);
+    run<24>("v_mul_f64", 1);
+    run<25>("v_fma_f64", 1);
+    run<31>("v_add_f64", 1);
+    run<26>("v_div_fixup_f32", 1);
+    run<27>("v_rcp_f32", 1);
+    run<28>("v_sqrt_f32", 1);
+    run<29>("v_exp_f32", 1);
+    run<30>("v_max3_f32", 1);
 }
