@@ -1,0 +1,26 @@
+"""Random-scene parity fuzz: the check of tests/test_gpu_parity.py::test_random_scenes_... over
+many seeds (default 400).  Prints every seed whose planes differ from the restatement."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ptk
+from oracle import oracle as O
+import test_gpu_parity as T
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    O.build()
+    ctx = ptk.Context(0)
+    bad = 0
+    for seed in range(100, 100 + n):
+        r = T.random_scene_mismatch(ctx, O, seed)
+        if r:
+            bad += 1
+            print("seed %d: %s" % (seed, r[:300]), flush=True)
+        if (seed - 99) % 50 == 0:
+            print("%d scenes, %d differ" % (seed - 99, bad), flush=True)
+    print("%d scenes, %d differ" % (n, bad))
+    return 1 if bad else 0
+
+if __name__ == "__main__":
+    sys.exit(main())
