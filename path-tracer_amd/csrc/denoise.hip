@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ptk_dev.h"
+#include "exact_div.h"
 
 #define DEV __device__ __forceinline__
 
@@ -44,28 +45,12 @@ DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896
 DEV float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// x / d for many x and one d, bit-identical to the IEEE quotient.  hipcc's
-// correctly rounded division is: (scale operands: identity unless an exponent
-// is extreme) r = rcp(d), one Newton step on r, q = x*r, two residual
-// corrections, v_div_fixup.  The first three operations depend on d only and
-// are shared here.  Denominators in this file are sample counts, 3*count, 49
-// and 9, all far inside the range where no scaling happens.
+// x / d for many x and one d, bit-identical to the IEEE quotient (exact_div.h).
+// Denominators in this file are sample counts, 3*count, 49 and 9, all far inside
+// the range where the compiler's division scales nothing.
 struct Recip { float r, d; };
-DEV Recip make_recip(float d)
-{
-    float r0 = __builtin_amdgcn_rcpf(d);
-    float e = __builtin_fmaf(-d, r0, 1.0f);
-    return {__builtin_fmaf(e, r0, r0), d};
-}
-DEV float div_by(float x, const Recip& R)
-{
-    float q = x * R.r;
-    float t = __builtin_fmaf(-R.d, q, x);
-    q = __builtin_fmaf(t, R.r, q);
-    t = __builtin_fmaf(-R.d, q, x);
-    q = __builtin_fmaf(t, R.r, q);
-    return __builtin_amdgcn_div_fixupf(q, R.d, x);
-}
+DEV Recip make_recip(float d) { return {ptk_exact::exact_reciprocal(d), d}; }
+DEV float div_by(float x, const Recip& R) { return ptk_exact::exact_quotient_fixup(x, R.r, R.d); }
 
 // The reference's "median getter" procedure (DenoiserNN.cpp:190-256).  It is
 // not a median: each pass pushes the nine values through a five-slot array
