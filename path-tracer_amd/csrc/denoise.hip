@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ptk_dev.h"
-#include "exact_div.h"
+#include "exact_ops.h"
 
 #define DEV __device__ __forceinline__
 
@@ -45,7 +45,7 @@ DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896
 DEV float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// x / d for many x and one d, bit-identical to the IEEE quotient (exact_div.h).
+// x / d for many x and one d, bit-identical to the IEEE quotient (exact_ops.h).
 // Denominators in this file are sample counts, 3*count, 49 and 9, all far inside
 // the range where the compiler's division scales nothing.
 struct Recip { float r, d; };
@@ -210,7 +210,9 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
             }
 #endif
         fk[2] = mean7;
-        fk[3] = __builtin_sqrtf(ss * (1.0f / 49.0f));
+        // the compiler's root without its rescaling of arguments below 2^-96 (exact_ops.h):
+        // the same bits above that, and this feature is compared within a tolerance
+        fk[3] = ptk_exact::exact_sqrt_unscaled(ss * (1.0f / 49.0f));
 
         float win[9];
         float mean3 = 0.0f;

@@ -1,4 +1,5 @@
-// exact_div.h -- correctly rounded fp32 quotients of many numerators by one denominator.
+// exact_ops.h -- correctly rounded fp32 quotients of many numerators by one denominator,
+// and the correctly rounded square root without the parts its callers cannot need.
 //
 // hipcc expands a correctly rounded a / d into: scale both operands (v_div_scale, the
 // identity unless an exponent is extreme), r = rcp(d), one Newton step on r, q = a*r, two
@@ -16,7 +17,7 @@
 // least 2^-24 / d ulp away from every midpoint; d*d < 4, so the last rounding lands on
 // RN(a / d).  scripts/check_exact_quotient.c compares the three operations with `/` on
 // the host for every numerator significand of many denominators, and
-// scripts/microbench/exact_div_check.hip does the same on the device, reciprocal included.
+// scripts/microbench/exact_ops_check.hip does the same on the device, reciprocal included.
 //
 // Valid while d is an ordinary number (exponent well inside the range: callers check,
 // or their denominators are sample counts and small constants) and nothing underflows;
@@ -50,6 +51,32 @@ __device__ __forceinline__ float exact_quotient(float a, float y, float d)
 __device__ __forceinline__ float exact_quotient_fixup(float a, float y, float d)
 {
     return __builtin_amdgcn_div_fixupf(exact_quotient(a, y, d), d, a);
+}
+
+// sqrt(x), bit-identical to the compiler's correctly rounded expansion for every x that is
+// NaN, a negative normal number, a zero of either sign, +infinity, or at least 2^-96 (a
+// negative subnormal gives -0 where the expansion gives NaN).  That expansion is:
+// multiply x by 2^32 when it is below 2^-96 (the hardware root is not accurate on the
+// smallest inputs), s = v_sqrt_f32 (within one unit in the last place), try the floats below
+// and above s -- the residuals x - (s -+ ulp)*s, each exact enough in one fma, say on which
+// side of s the root lies -- undo the scaling, and return x itself for zeros and infinity.
+// Here the scaling and the class test are left out: 9 instructions instead of 16, five of the
+// seven dropped being compares and selects.  Zeros and infinity still come out right
+// (the neighbours of 0 and of infinity give residuals that are NaN or zero, which select
+// nothing), and a negative x gives the NaN the full expansion gives.  Callers either know
+// their argument cannot lie in (0, 2^-96) -- a difference 1 - y is a multiple of 2^-24, a
+// uniform variate a multiple of 2^-64, a value that is discarded below a threshold -- or check
+// the result's exponent and redo the work with the compiler's sqrt (vnormalize).
+__device__ __forceinline__ float exact_sqrt_unscaled(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __int_as_float(__float_as_int(s) - 1);
+    const float above = __int_as_float(__float_as_int(s) + 1);
+    const float r_below = __builtin_fmaf(-below, s, x);
+    const float r_above = __builtin_fmaf(-above, s, x);
+    float r = (r_below <= 0.0f) ? below : s;
+    r = (r_above > 0.0f) ? above : r;
+    return r;
 }
 
 }  // namespace ptk_exact

@@ -1,4 +1,5 @@
-// Device check of csrc/exact_div.h: exact_reciprocal(d) against 1.0f / d for every significand
+// Device check of csrc/exact_ops.h: exact_sqrt_unscaled(x) against sqrtf(x) for every float x outside
+// (0, 2^-96) and the negative subnormals (all other bit patterns); exact_reciprocal(d) against 1.0f / d for every significand
 // of d at several exponents, and exact_quotient / exact_quotient_fixup against a / d for every
 // significand of d with pseudo-random numerators (and, for a few denominators, every numerator
 // significand).  Prints the number of differences; exit status 1 if any.
@@ -6,7 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include "../../path-tracer_amd/csrc/exact_div.h"
+#include "../../path-tracer_amd/csrc/exact_ops.h"
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 __device__ inline uint64_t mix(uint64_t z)
@@ -59,9 +60,28 @@ __global__ void special_numerators(unsigned long long* counts)
         }
 }
 
+// counts[3]: roots that differ, over all 2^32 bit patterns outside (0, 2^-96); NaN equals NaN
+__global__ void sweep_sqrt(unsigned long long* counts)
+{
+    const uint32_t hi = blockIdx.x * blockDim.x + threadIdx.x;   // 2^24 threads, 256 patterns each
+    unsigned bad = 0;
+    for (uint32_t lo = 0; lo < 256; lo++) {
+        const uint32_t bits = (hi << 8) | lo;
+        const float x = __uint_as_float(bits);
+        if (x > 0.0f && x < 1.2621774e-29f) continue;            // (0, 2^-96): outside the contract
+        if (x < 0.0f && x > -1.17549435e-38f) continue;           // negative subnormals: -0 here, NaN there
+        float xv = x;
+        asm volatile("" : "+v"(xv));                              // keep the two roots apart
+        const float got = ptk_exact::exact_sqrt_unscaled(x), want = __builtin_sqrtf(xv);
+        const bool same = (got != got && want != want) || __float_as_uint(got) == __float_as_uint(want);
+        bad += !same;
+    }
+    if (bad) atomicAdd(&counts[3], (unsigned long long)bad);
+}
+
 int main()
 {
-    unsigned long long* counts; unsigned long long h[3] = {0, 0, 0};
+    unsigned long long* counts; unsigned long long h[4] = {0, 0, 0, 0};
     CHECK(hipMalloc(&counts, sizeof h));
     CHECK(hipMemset(counts, 0, sizeof h));
     const int exps[] = {-47, -30, -8, -1, 0, 1, 7, 23, 30, 47};
@@ -69,11 +89,13 @@ int main()
     const float few[] = {3.0f, 9.0f, 49.0f, 128.0f, 384.0f, 1.9999999f, 1.0000001f, 0.7071068f, 5592405.0f * 3.0f};
     for (float d : few) hipLaunchKernelGGL(sweep_numerators, dim3((1u << 23) / 256), dim3(256), 0, 0, d, counts);
     hipLaunchKernelGGL(special_numerators, dim3(1), dim3(1), 0, 0, counts);
+    hipLaunchKernelGGL(sweep_sqrt, dim3((1u << 24) / 256), dim3(256), 0, 0, counts);
     CHECK(hipDeviceSynchronize());
     CHECK(hipMemcpy(h, counts, sizeof h, hipMemcpyDeviceToHost));
     printf("exact_reciprocal vs 1.0f / d: %llu of %d x 2^23 denominators differ\n", h[0], (int)(sizeof exps / sizeof exps[0]));
     printf("exact_quotient vs a / d: %llu of %.3g quotients differ\n", h[1],
            (double)(sizeof exps / sizeof exps[0]) * 8388608.0 * 48 + (double)(sizeof few / sizeof few[0]) * 8388608.0);
     printf("exact_quotient_fixup vs a / d (zeros, infinities, NaN included): %llu differ\n", h[2]);
-    return h[0] || h[1] || h[2] ? 1 : 0;
+    printf("exact_sqrt_unscaled vs sqrtf, every float but (0, 2^-96) and negative subnormals: %llu differ\n", h[3]);
+    return h[0] || h[1] || h[2] || h[3] ? 1 : 0;
 }
