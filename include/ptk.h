@@ -207,7 +207,9 @@ int ptk_set_stream_id(ptk_ctx* ctx, uint64_t stream_id);
  * Renderers.cpp:845-888) fused into the kernel: each pass increments
  * sampleCount, traces one path per pixel and updates all planes.
  * seed_mode PTK_SEED_REFERENCE advances glo_seed exactly spp*width*height
- * steps of the reference's recurrence (in-out, must be non-null);
+ * steps of the reference's recurrence (in-out, must be non-null); the
+ * seeds are generated on the host and staged through at most 256 MiB of
+ * device and of pinned host memory (PTK_ERR_NOMEM if that cannot be had);
  * PTK_SEED_COUNTER ignores glo_seed.  rays_out (optional) receives the bounce
  * rays of the whole call (the reference's rayCount for spp == 1). */
 int ptk_render(ptk_ctx* ctx, int spp, int seed_mode, uint64_t glo_seed[2], uint64_t* rays_out);

@@ -38,8 +38,11 @@ int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                             \
     } while (0)
 
-// Seed passes are uploaded in chunks of at most this many bytes, and of one whole pass at
-// least (16 bytes per pixel: 133 MB at 4K, 531 MB at 8K).
+// Reference seeds (16 bytes per pixel per pass: 133 MB at 4K, 531 MB at 8K) are staged in
+// pieces of at most this many bytes, device and pinned host each: several whole passes, or
+// one pass in bands of rows when a pass is larger.  The environment variable
+// PTK_SEED_CHUNK_BYTES, read when a context is created, overrides it (the tests use it to
+// drive the band path at small sizes).
 constexpr size_t SEED_CHUNK_BYTES = size_t(256) << 20;
 
 }  // namespace
@@ -70,7 +73,8 @@ struct ptk_ctx {
     float* planes_d = nullptr;        // PTK_N_PLANES * pixels
     int64_t* seeds_d = nullptr;       // seed chunk
     int64_t* seeds_h = nullptr;       // pinned staging for the chunk
-    size_t seed_capacity = 0;         // in passes
+    size_t seed_capacity = 0;         // in seeds (16 bytes each)
+    size_t seed_chunk_bytes = SEED_CHUNK_BYTES;
     unsigned long long* rays_d = nullptr;
     double* sum_d = nullptr;
 
@@ -351,6 +355,10 @@ int ptk_create(int device, ptk_ctx** out)
     if (!c) return fail(PTK_ERR_NOMEM, "ptk_create: out of host memory");
     c->device = device;
     std::memset(&c->times, 0, sizeof c->times);
+    if (const char* v = std::getenv("PTK_SEED_CHUNK_BYTES")) {
+        const unsigned long long b = std::strtoull(v, nullptr, 10);
+        if (b >= 16) c->seed_chunk_bytes = (size_t)b;
+    }
     int rc = bind(c);
     if (rc != PTK_OK) { delete c; return rc; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -861,6 +869,10 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     a.width = c->width;
     a.height = c->height;
     a.has_blur = c->has_blur ? 1 : 0;
+    a.row_begin = 0;
+    a.row_end = c->height;
+    a.seed_pixel0 = 0;
+    a.seed_stride = (int64_t)P;
     a.big = c->big;
     auto launch = c->big_scene ? (c->math_mode == PTK_MATH_FAST ? ptk_launch_render_bvh_fast
                                                                  : ptk_launch_render_bvh_exact)
@@ -878,26 +890,38 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
         render_ms = elapsed_ms(c);
         c->sample_count += spp;
     } else {
-        size_t per_pass = P * 2 * sizeof(int64_t);
-        size_t want = SEED_CHUNK_BYTES / per_pass;
-        if (want < 1) want = 1;
-        if (want > (size_t)spp) want = (size_t)spp;
+        // The global seed recurrence is sequential (Renderers.cpp:1051-1060), so the host steps
+        // it and stages 16 bytes per pixel per pass: whole passes while they fit in
+        // the chunk size, otherwise one pass in bands of rows (a multiple of 16, the
+        // workgroup's height), which the recurrence's row-major pixel order allows.
+        const size_t per_pass = P * 2 * sizeof(int64_t);
+        const size_t W = (size_t)c->width;
+        size_t band_rows = (size_t)c->height;          // rows per launch
+        size_t passes = c->seed_chunk_bytes / per_pass;   // passes per launch
+        if (passes < 1) {
+            passes = 1;
+            band_rows = c->seed_chunk_bytes / (W * 2 * sizeof(int64_t)) / 16 * 16;
+            if (band_rows < 16) band_rows = 16;
+            if (band_rows > (size_t)c->height) band_rows = (size_t)c->height;
+        }
+        if (passes > (size_t)spp) passes = (size_t)spp;
+        const size_t want = passes * band_rows * W;    // seeds (pairs) staged at a time
         if (want > c->seed_capacity) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             (void)hipFree(c->seeds_d); c->seeds_d = nullptr;
             if (c->seeds_h) (void)hipHostFree(c->seeds_h);
             c->seeds_h = nullptr;
             c->seed_capacity = 0;
-            // one whole pass at least: 16 bytes per pixel, device and pinned host
-            hipError_t ea = hipMalloc((void**)&c->seeds_d, want * per_pass);
+            const size_t bytes = want * 2 * sizeof(int64_t);
+            hipError_t ea = hipMalloc((void**)&c->seeds_d, bytes);
             if (ea == hipSuccess)
-                ea = hipHostMalloc((void**)&c->seeds_h, want * per_pass, hipHostMallocDefault);
+                ea = hipHostMalloc((void**)&c->seeds_h, bytes, hipHostMallocDefault);
             if (ea != hipSuccess) {
                 (void)hipFree(c->seeds_d); c->seeds_d = nullptr;
                 (void)hipGetLastError();
                 return fail(ea == hipErrorOutOfMemory ? PTK_ERR_NOMEM : PTK_ERR_HIP,
                             "ptk_render: %zu bytes of seed staging (reference seeds take 16 bytes "
-                            "per pixel per pass): %s", want * per_pass, hipGetErrorString(ea));
+                            "per pixel per pass): %s", bytes, hipGetErrorString(ea));
             }
             c->seed_capacity = want;
         }
@@ -905,28 +929,36 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
         int done = 0;
         while (done < spp) {
             int chunk = spp - done;
-            if ((size_t)chunk > c->seed_capacity) chunk = (int)c->seed_capacity;
-            timespec t0, t1;
-            clock_gettime(CLOCK_MONOTONIC, &t0);
-            int64_t* h = c->seeds_h;
-            const size_t n = (size_t)chunk * P;
-            for (size_t i = 0; i < n; i++) {
-                seed_step(g0, g1);
-                h[2 * i] = (int64_t)g0;
-                h[2 * i + 1] = (int64_t)g1;
+            if ((size_t)chunk > passes) chunk = (int)passes;
+            for (size_t row0 = 0; row0 < (size_t)c->height; row0 += band_rows) {
+                const size_t row1 = std::min(row0 + band_rows, (size_t)c->height);
+                const size_t band_pixels = (row1 - row0) * W;   // == P unless a pass is split
+                timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                int64_t* h = c->seeds_h;
+                const size_t n = (size_t)chunk * band_pixels;
+                for (size_t i = 0; i < n; i++) {
+                    seed_step(g0, g1);
+                    h[2 * i] = (int64_t)g0;
+                    h[2 * i + 1] = (int64_t)g1;
+                }
+                HIP_TRY(hipMemcpyAsync(c->seeds_d, h, n * 2 * sizeof(int64_t),
+                                       hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                seed_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+                a.seeds = c->seeds_d;
+                a.spp = chunk;
+                a.base_count = c->sample_count;
+                a.row_begin = (int32_t)row0;
+                a.row_end = (int32_t)row1;
+                a.seed_pixel0 = (int64_t)(row0 * W);
+                a.seed_stride = (int64_t)band_pixels;
+                HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+                HIP_TRY(launch(a, c->max_depth, c->features, c->stream));
+                HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+                render_ms += elapsed_ms(c);
             }
-            HIP_TRY(hipMemcpyAsync(c->seeds_d, h, n * 2 * sizeof(int64_t), hipMemcpyHostToDevice,
-                                   c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            seed_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-            a.seeds = c->seeds_d;
-            a.spp = chunk;
-            a.base_count = c->sample_count;
-            HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-            HIP_TRY(launch(a, c->max_depth, c->features, c->stream));
-            HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-            render_ms += elapsed_ms(c);
             c->sample_count += chunk;
             done += chunk;
         }

@@ -106,13 +106,18 @@ struct BigScene {
 struct RenderArgs {
     const DevScene* scene;   // device memory
     float* planes;           // PTK_N_PLANES * P floats
-    const int64_t* seeds;    // seed mode 0: [pass][pixel][2]; null in counter mode
+    const int64_t* seeds;    // seed mode 0: [pass][pixel - seed_pixel0][2]; null in counter mode
     unsigned long long* rays; // device counter, incremented by the call's bounce rays
     uint64_t stream_id;      // counter mode
     int32_t width, height;
     int32_t spp;             // passes in this launch
     int32_t base_count;      // sampleCount before this launch
     int32_t has_blur;        // some shape's material has blur > 0
+    // Rows [row_begin, row_end) are rendered (the image, or a band of it when one pass of
+    // reference seeds is staged in pieces); row_begin is a multiple of 16.  The seed of pass s
+    // for pixel p is at seeds[(s * seed_stride + p - seed_pixel0) * 2].
+    int32_t row_begin, row_end;
+    int64_t seed_pixel0, seed_stride;
     BigScene big;            // ptk_set_scene scenes only (render_bvh_*.hip)
 };
 

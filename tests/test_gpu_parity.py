@@ -717,3 +717,39 @@ def test_random_scenes_are_bit_identical_to_the_correctly_rounded_restatement(ct
     plane of every pixel equals variant R of the restatement bit for bit, and the generator
     state matches.  scripts/gpu_scene_fuzz.py runs the same check over hundreds of seeds."""
     assert random_scene_mismatch(ctx, oracle, seed) == ""
+
+
+def test_reference_seeds_staged_in_row_bands_give_the_same_frame(oracle, monkeypatch):
+    """A pass of reference seeds larger than the staging chunk is rendered in bands of rows
+    (multiples of 16), the global recurrence running on across bands in pixel order: planes,
+    seed state and ray count equal those of whole-pass staging, with and without features."""
+    import ptk
+    O = oracle
+    W, H = 37, 50                                        # bands of 16, 16, 16 and 2 rows
+    sc = O.load_scene(scene_path("MultiLightGlass"))
+    results = []
+    for chunk in (None, 37 * 16 * 16 + 100, 16):          # whole passes; 16-row bands; below one band
+        if chunk is None:
+            monkeypatch.delenv("PTK_SEED_CHUNK_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("PTK_SEED_CHUNK_BYTES", str(chunk))
+        c = ptk.Context(0)
+        try:
+            per_feat = []
+            for feats in (False, True):
+                c.set_constants(O.build_constants(sc, W, H, 4, 0.005, feats))
+                rays, glo = c.render(3, ptk.SEED_REFERENCE, PIN_SEED)
+                rays2, glo2 = c.render(2, ptk.SEED_REFERENCE, glo)      # a second call continues
+                per_feat.append((rays + rays2, glo2, c.read_planes()))
+            results.append(per_feat)
+        finally:
+            c.close()
+    for other in results[1:]:
+        for (r0, g0, p0), (r1, g1, p1) in zip(results[0], other):
+            assert r0 == r1 and g0 == g1
+            assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+    acc = O.new_accumulators(W, H)
+    with O.variant("R"):
+        n, glo, _ = O.render(O.build_constants(sc, W, H, 4, 0.005, True), acc, 5, 0, PIN_SEED, threads=4)
+    assert glo == results[0][1][1]
+    assert _same(results[1][1][2], acc).all()
