@@ -68,6 +68,7 @@ struct ptk_ctx {
     BigScene big = {};
     void* big_alloc[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool has_blur = false;
+    bool ordered_boxes = true;        // every box has lo <= hi on every axis
     double big_extent = 0.0;          // what a ptk_set_scene scene's bounds were padded for
 
     float* planes_d = nullptr;        // PTK_N_PLANES * pixels
@@ -420,8 +421,14 @@ int ptk_set_constants(ptk_ctx* c, const void* constants, size_t nbytes, int want
     c->max_depth = k.max_depth;
     c->features = feats != 0;
     c->has_blur = false;
-    for (int i = 0; i < d.num_shapes; i++)
+    c->ordered_boxes = true;
+    for (int i = 0; i < d.num_shapes; i++) {
         if (d.mats[d.shape[i].mat][3] > 0.0f) c->has_blur = true;
+        if (d.shape[i].type == 1)
+            for (int k3 = 0; k3 < 3; k3++)
+                if (!(d.shape[i].lo[k3] <= d.shape[i].hi[k3])) c->ordered_boxes = false;
+    }
+    c->host_scene.ordered_boxes = c->ordered_boxes ? 1 : 0;
     HIP_TRY(hipMemcpyAsync(c->scene_d, &c->host_scene, sizeof(DevScene), hipMemcpyHostToDevice,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -442,7 +449,7 @@ struct HostBigScene {
     std::vector<LeafRec> recs;
     std::vector<float> blo, bhi;      // padded bounds per shape
     BvhBuild bvh;
-    bool has_blur = false, any_dielectric = false;
+    bool has_blur = false, any_dielectric = false, ordered_boxes = true;
     double build_ms = 0.0;
     double extent = 0.0;
 };
@@ -529,6 +536,9 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
         const float* m = k->mat_list + (size_t)mat * 6;
         has_blur = has_blur || m[3] > 0.0f;
         any_dielectric = any_dielectric || (int)m[5] == 3;
+        if (type == 1)
+            for (int i = 0; i < 3; i++)
+                if (!(at[3 + i] <= at[6 + i])) H.ordered_boxes = false;
         for (int i = 0; i < (type == 0 ? 3 : 9); i++) extent = std::max(extent, (double)std::fabs(at[i]));
         if (type == 0) extent = std::max(extent, (double)std::fabs(at[3]));
     }
@@ -775,7 +785,9 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     c->big_scene = true;
     c->big_extent = H.extent;
     c->has_blur = has_blur;
+    c->ordered_boxes = H.ordered_boxes;
     c->host_scene = d;
+    c->host_scene.ordered_boxes = H.ordered_boxes ? 1 : 0;
     c->max_depth = k->max_depth;
     c->features = feats != 0;
     HIP_TRY(hipMemcpyAsync(c->scene_d, &c->host_scene, sizeof(DevScene), hipMemcpyHostToDevice,

@@ -51,6 +51,7 @@ struct DevScene {
     int32_t imp[PTK_MAX_IMPORTANT];
     float inv_depth;   // 1.0f / (float)max_depth
     float imp_boost;   // (float)num_imp when num_imp > 1, else 1
+    int32_t ordered_boxes;   // every box has lo <= hi on every axis (the merged slab test needs it)
     DevShape shape[PTK_MAX_SHAPES];
     float mats[PTK_MAX_MATS][6];
     // Per shape, the sixteen sums of quaternion components that the two

@@ -642,7 +642,7 @@ def test_full_tables_fifty_shapes_fifty_materials(ctx, oracle):
     assert _mismatch_report(planes, acc_r, 48) == ""
 
 
-def random_pod_scene(O, seed, W=40, H=24):
+def random_pod_scene(O, seed, W=40, H=24, swap_bounds=False):
     """A random scene built straight into the POD: 3 to 24 shapes (axis-aligned, flat and rotated
     boxes, several snapped to a coarse grid through the origin so that slab numerators and hit
     coordinates are exact zeros; spheres), all four material kinds, blur on some, lights as
@@ -676,7 +676,11 @@ def random_pod_scene(O, seed, W=40, H=24):
                 half[int(rng.integers(0, 3))] = 0.0       # flat
             q = rng.normal(size=4) if rng.random() < 0.4 else np.array([1.0, 0, 0, 0])
             q /= np.linalg.norm(q)
-            attrs = (*pos, *(pos - half), *(pos + half), *q)
+            lo, hi = pos - half, pos + half
+            if swap_bounds and rng.random() < 0.5:        # a malformed box: lo > hi on one axis
+                ax = int(rng.integers(0, 3))
+                lo[ax], hi[ax] = hi[ax], lo[ax]
+            attrs = (*pos, *lo, *hi, *q)
             c.shapes[s][0] = 1
         else:
             attrs = (*pos, float(rng.uniform(0.3, 1.5)))
@@ -697,9 +701,9 @@ def random_pod_scene(O, seed, W=40, H=24):
     return c
 
 
-def random_scene_mismatch(ctx, O, seed, W=40, H=24):
+def random_scene_mismatch(ctx, O, seed, W=40, H=24, swap_bounds=False):
     import ptk
-    c = random_pod_scene(O, seed, W, H)
+    c = random_pod_scene(O, seed, W, H, swap_bounds)
     with O.variant("R"):
         acc = O.new_accumulators(W, H)
         n, glo, rays = O.render(c, acc, 2, 0, PIN_SEED, threads=4)
@@ -753,3 +757,13 @@ def test_reference_seeds_staged_in_row_bands_give_the_same_frame(oracle, monkeyp
         n, glo, _ = O.render(O.build_constants(sc, W, H, 4, 0.005, True), acc, 5, 0, PIN_SEED, threads=4)
     assert glo == results[0][1][1]
     assert _same(results[1][1][2], acc).all()
+
+
+@pytest.mark.parametrize("seed", range(50, 56))
+def test_boxes_with_swapped_bounds_take_the_reference_comparison_chain(ctx, oracle, seed):
+    """The slab test merges the three axes with max / min when every box of the scene has
+    lo <= hi; a scene with a malformed box (lo > hi on an axis) must fall back to the
+    reference's chain of comparisons, whose outcome for such a box is its own: every plane
+    bit-identical to the correctly rounded restatement."""
+    r = random_scene_mismatch(ctx, oracle, seed, swap_bounds=True)
+    assert not r, r
