@@ -318,6 +318,20 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
         compile_shape(type, mat, (int)k.mat_list[mat][5], k.obj_attributes + a, d.shape[s], d.rot[s],
                       d.face_normal[s], d.scan[s]);
     }
+    // the records again, grouped by kind (see DevScene::scan_kind)
+    int at = 0;
+    d.n_plain = d.n_rotated = d.n_spheres = d.any_dielectric = 0;
+    for (int kind = 0; kind < 3; kind++)
+        for (int s = 0; s < k.num_shapes; s++) {
+            const ScanRec& r = d.scan[s];
+            const int its = r.type != 1 ? 2 : (r.rotated ? 1 : 0);
+            if (its != kind) continue;
+            d.scan_kind[at] = r;
+            d.scan_kind[at].index = s;
+            at++;
+            (kind == 0 ? d.n_plain : kind == 1 ? d.n_rotated : d.n_spheres)++;
+            if (r.mat_type == 3) d.any_dielectric = 1;
+        }
     return PTK_OK;
 }
 
@@ -886,10 +900,12 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     a.seed_pixel0 = 0;
     a.seed_stride = (int64_t)P;
     a.big = c->big;
-    auto launch = c->big_scene ? (c->math_mode == PTK_MATH_FAST ? ptk_launch_render_bvh_fast
-                                                                 : ptk_launch_render_bvh_exact)
-                               : (c->math_mode == PTK_MATH_FAST ? ptk_launch_render_fast
-                                                                 : ptk_launch_render_exact);
+    // A scene in which nothing refracts may be scanned in any order (see DevScene::scan_kind).
+    const bool by_kind = !c->big_scene && !c->host_scene.any_dielectric;
+    const bool fast = c->math_mode == PTK_MATH_FAST;
+    auto launch = c->big_scene ? (fast ? ptk_launch_render_bvh_fast : ptk_launch_render_bvh_exact)
+                  : by_kind    ? (fast ? ptk_launch_render_kind_fast : ptk_launch_render_kind_exact)
+                               : (fast ? ptk_launch_render_fast : ptk_launch_render_exact);
 
     double render_ms = 0.0, seed_ms = 0.0;
     if (seed_mode == PTK_SEED_COUNTER) {

@@ -39,7 +39,7 @@ struct alignas(64) ScanRec {
     float c[3], lo[3], hi[3];
     float rsq;
     int32_t type, rotated, same_mask, mat_type, mat;
-    int32_t index;   // the shape's index, in the in-register copies the hierarchy walks make; 0 in DevScene::scan
+    int32_t index;   // the shape's index (DevScene::scan_kind and the hierarchy walks' copies); 0 in DevScene::scan
 };
 static_assert(sizeof(ScanRec) == 64, "ScanRec must be 16 dwords");
 
@@ -65,6 +65,12 @@ struct DevScene {
     // the kernel's order (Renderers.cpp:25-47, 262-267).
     float face_normal[PTK_MAX_SHAPES][7][3];
     ScanRec scan[PTK_MAX_SHAPES + 1];   // one past the end so the look-ahead load is always valid
+    // The same records grouped by kind -- unrotated boxes, rotated boxes, spheres, each group in
+    // index order and carrying its index -- so that a scan can run one straight loop per kind.
+    // The closest-hit scan always may (ties go to the lower index either way); a shadow scan
+    // may when no shape refracts (any_dielectric == 0), because then its order does not matter.
+    ScanRec scan_kind[PTK_MAX_SHAPES + 1];
+    int32_t n_plain, n_rotated, n_spheres, any_dielectric;
 };
 
 // ---- scenes beyond the POD's limits (ptk_set_scene): the shapes live in HBM
@@ -128,6 +134,11 @@ hipError_t ptk_launch_render_exact(const RenderArgs& a, int max_depth, bool feat
                                    hipStream_t stream);
 hipError_t ptk_launch_render_fast(const RenderArgs& a, int max_depth, bool features,
                                   hipStream_t stream);
+// The same for scenes in which no shape refracts (DevScene::any_dielectric == 0): scans by kind of shape.
+hipError_t ptk_launch_render_kind_exact(const RenderArgs& a, int max_depth, bool features,
+                                        hipStream_t stream);
+hipError_t ptk_launch_render_kind_fast(const RenderArgs& a, int max_depth, bool features,
+                                       hipStream_t stream);
 hipError_t ptk_launch_render_bvh_exact(const RenderArgs& a, int max_depth, bool features,
                                        hipStream_t stream);
 hipError_t ptk_launch_render_bvh_fast(const RenderArgs& a, int max_depth, bool features,
