@@ -76,6 +76,7 @@ struct ptk_ctx {
     int64_t* seeds_h = nullptr;       // pinned staging for the chunk
     size_t seed_capacity = 0;         // in seeds (16 bytes each)
     size_t seed_chunk_bytes = SEED_CHUNK_BYTES;
+    bool index_order_only = false;    // PTK_INDEX_ORDER_SCANS=1: never the by-kind kernels (measurements, tests)
     unsigned long long* rays_d = nullptr;
     double* sum_d = nullptr;
 
@@ -370,6 +371,7 @@ int ptk_create(int device, ptk_ctx** out)
     if (!c) return fail(PTK_ERR_NOMEM, "ptk_create: out of host memory");
     c->device = device;
     std::memset(&c->times, 0, sizeof c->times);
+    if (const char* v = std::getenv("PTK_INDEX_ORDER_SCANS")) c->index_order_only = v[0] == '1';
     if (const char* v = std::getenv("PTK_SEED_CHUNK_BYTES")) {
         const unsigned long long b = std::strtoull(v, nullptr, 10);
         if (b >= 16) c->seed_chunk_bytes = (size_t)b;
@@ -901,7 +903,7 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     a.seed_stride = (int64_t)P;
     a.big = c->big;
     // A scene in which nothing refracts may be scanned in any order (see DevScene::scan_kind).
-    const bool by_kind = !c->big_scene && !c->host_scene.any_dielectric;
+    const bool by_kind = !c->big_scene && !c->host_scene.any_dielectric && !c->index_order_only;
     const bool fast = c->math_mode == PTK_MATH_FAST;
     auto launch = c->big_scene ? (fast ? ptk_launch_render_bvh_fast : ptk_launch_render_bvh_exact)
                   : by_kind    ? (fast ? ptk_launch_render_kind_fast : ptk_launch_render_kind_exact)

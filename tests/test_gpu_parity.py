@@ -767,3 +767,29 @@ def test_boxes_with_swapped_bounds_take_the_reference_comparison_chain(ctx, orac
     bit-identical to the correctly rounded restatement."""
     r = random_scene_mismatch(ctx, oracle, seed, swap_bounds=True)
     assert not r, r
+
+
+@pytest.mark.parametrize("name", ["cornell", "Box_Grid", "bars3"])
+def test_scans_by_kind_equal_scans_in_index_order(oracle, monkeypatch, name):
+    """Scenes in which no shape refracts are rendered by the kernels that scan the shapes kind by
+    kind (unrotated boxes, rotated boxes, spheres); PTK_INDEX_ORDER_SCANS=1 keeps a context on
+    the index-order kernels.  Same planes, ray count and seed state, features included."""
+    import ptk
+    O = oracle
+    W, H = 96, 54
+    consts = O.build_constants(O.load_scene(scene_path(name)), W, H, 4, 0.005, True)
+    out = []
+    for index_order in (False, True):
+        if index_order:
+            monkeypatch.setenv("PTK_INDEX_ORDER_SCANS", "1")
+        else:
+            monkeypatch.delenv("PTK_INDEX_ORDER_SCANS", raising=False)
+        c = ptk.Context(0)
+        try:
+            c.set_constants(consts)
+            rays, glo = c.render(3, ptk.SEED_REFERENCE, PIN_SEED)
+            out.append((rays, glo, c.read_planes()))
+        finally:
+            c.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32))
