@@ -76,7 +76,7 @@ struct ptk_ctx {
     int64_t* seeds_h = nullptr;       // pinned staging for the chunk
     size_t seed_capacity = 0;         // in seeds (16 bytes each)
     size_t seed_chunk_bytes = SEED_CHUNK_BYTES;
-    bool index_order_only = false;    // PTK_INDEX_ORDER_SCANS=1: never the by-kind kernels (measurements, tests)
+    bool segment_scans_only = false;  // PTK_SEGMENT_SCANS=1: the kernels with the bending code for every scene (tests)
     unsigned long long* rays_d = nullptr;
     double* sum_d = nullptr;
 
@@ -333,6 +333,32 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
             (kind == 0 ? d.n_plain : kind == 1 ? d.n_rotated : d.n_spheres)++;
             if (r.mat_type == 3) d.any_dielectric = 1;
         }
+    // and by stretches between refracting shapes (see DevScene::scan_seg)
+    at = 0;
+    d.n_segments = 0;
+    for (int s0 = 0; s0 < k.num_shapes;) {
+        int s1 = s0;
+        while (s1 < k.num_shapes && d.scan[s1].mat_type != 3) s1++;
+        DevScene::Segment& g = d.seg[d.n_segments++];
+        g.n_plain = g.n_rotated = g.n_spheres = 0;
+        for (int kind = 0; kind < 3; kind++)
+            for (int s = s0; s < s1; s++) {
+                const ScanRec& r = d.scan[s];
+                const int its = r.type != 1 ? 2 : (r.rotated ? 1 : 0);
+                if (its != kind) continue;
+                d.scan_seg[at] = r;
+                d.scan_seg[at].index = s;
+                at++;
+                (kind == 0 ? g.n_plain : kind == 1 ? g.n_rotated : g.n_spheres)++;
+            }
+        g.ends_refracting = s1 < k.num_shapes ? 1 : 0;
+        if (g.ends_refracting) {
+            d.scan_seg[at] = d.scan[s1];
+            d.scan_seg[at].index = s1;
+            at++;
+        }
+        s0 = s1 + 1;
+    }
     return PTK_OK;
 }
 
@@ -371,7 +397,7 @@ int ptk_create(int device, ptk_ctx** out)
     if (!c) return fail(PTK_ERR_NOMEM, "ptk_create: out of host memory");
     c->device = device;
     std::memset(&c->times, 0, sizeof c->times);
-    if (const char* v = std::getenv("PTK_INDEX_ORDER_SCANS")) c->index_order_only = v[0] == '1';
+    if (const char* v = std::getenv("PTK_SEGMENT_SCANS")) c->segment_scans_only = v[0] == '1';
     if (const char* v = std::getenv("PTK_SEED_CHUNK_BYTES")) {
         const unsigned long long b = std::strtoull(v, nullptr, 10);
         if (b >= 16) c->seed_chunk_bytes = (size_t)b;
@@ -902,8 +928,9 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     a.seed_pixel0 = 0;
     a.seed_stride = (int64_t)P;
     a.big = c->big;
-    // A scene in which nothing refracts may be scanned in any order (see DevScene::scan_kind).
-    const bool by_kind = !c->big_scene && !c->host_scene.any_dielectric && !c->index_order_only;
+    // A scene in which nothing refracts needs no bending code in its shadow scans (see
+    // PTK_KIND_LOOPS in render_kernel.inc): kernels without it, 1 to 2 % faster.
+    const bool by_kind = !c->big_scene && !c->host_scene.any_dielectric && !c->segment_scans_only;
     const bool fast = c->math_mode == PTK_MATH_FAST;
     auto launch = c->big_scene ? (fast ? ptk_launch_render_bvh_fast : ptk_launch_render_bvh_exact)
                   : by_kind    ? (fast ? ptk_launch_render_kind_fast : ptk_launch_render_kind_exact)

@@ -71,6 +71,14 @@ struct DevScene {
     // may when no shape refracts (any_dielectric == 0), because then its order does not matter.
     ScanRec scan_kind[PTK_MAX_SHAPES + 1];
     int32_t n_plain, n_rotated, n_spheres, any_dielectric;
+    // For shadow scans of scenes WITH refracting shapes: a refracting shape bends the ray for
+    // the shapes after it, so the order is free only between two of them.  scan_seg holds, for
+    // each stretch of the index order that ends at a refracting shape (or at the last shape),
+    // the stretch's other shapes grouped by kind and then that refracting shape; seg[i] says
+    // how many of each there are.
+    ScanRec scan_seg[PTK_MAX_SHAPES + 1];
+    struct Segment { int32_t n_plain, n_rotated, n_spheres, ends_refracting; } seg[PTK_MAX_SHAPES + 1];
+    int32_t n_segments, pad_seg[3];
 };
 
 // ---- scenes beyond the POD's limits (ptk_set_scene): the shapes live in HBM

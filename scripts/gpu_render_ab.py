@@ -18,12 +18,12 @@ for scene, feats in (("cornell_crystal", False), ("cornell", False), ("bars3", F
     print("  %%-16s feats=%%d  median %%.0f  min %%.0f max %%.0f Msamples/s" %% (scene, feats, statistics.median(r), min(r), max(r)), flush=True)
 ''' % ROOT
 libs = [""] + sorted(glob.glob(os.path.join(ROOT, "path-tracer_amd", "variants", "*.so")))
-if len(sys.argv) > 1 and sys.argv[1] == "index-order":     # the default library with and without its by-kind kernels
-    libs = ["", "PTK_INDEX_ORDER_SCANS"]
+if len(sys.argv) > 1 and sys.argv[1] == "segment-scans":   # the default library with and without its kernels for scenes that refract nothing
+    libs = ["", "PTK_SEGMENT_SCANS"]
 for rnd in range(2):
     for lib in libs:
         print("==", os.path.basename(lib) or "libptk.so (default)", "round", rnd, flush=True)
         env = dict(os.environ)
-        if lib == "PTK_INDEX_ORDER_SCANS": env[lib] = "1"
+        if lib == "PTK_SEGMENT_SCANS": env[lib] = "1"
         elif lib: env["PTK_LIB"] = lib
         subprocess.run([sys.executable, "-c", code], env=env, timeout=300)

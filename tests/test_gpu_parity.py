@@ -769,21 +769,22 @@ def test_boxes_with_swapped_bounds_take_the_reference_comparison_chain(ctx, orac
     assert not r, r
 
 
-@pytest.mark.parametrize("name", ["cornell", "Box_Grid", "bars3"])
-def test_scans_by_kind_equal_scans_in_index_order(oracle, monkeypatch, name):
-    """Scenes in which no shape refracts are rendered by the kernels that scan the shapes kind by
-    kind (unrotated boxes, rotated boxes, spheres); PTK_INDEX_ORDER_SCANS=1 keeps a context on
-    the index-order kernels.  Same planes, ray count and seed state, features included."""
+@pytest.mark.parametrize("name", ["cornell", "Box_Grid", "basic"])
+def test_both_kernel_families_render_a_scene_without_refraction_alike(oracle, monkeypatch, name):
+    """Scenes in which no shape refracts are rendered by kernels whose shadow scans carry no
+    bending code; PTK_SEGMENT_SCANS=1 keeps a context on the kernels for scenes that do refract
+    (shadow scans by stretches between refracting shapes: here one stretch).  Same planes, ray
+    count and seed state, features included."""
     import ptk
     O = oracle
     W, H = 96, 54
     consts = O.build_constants(O.load_scene(scene_path(name)), W, H, 4, 0.005, True)
     out = []
-    for index_order in (False, True):
-        if index_order:
-            monkeypatch.setenv("PTK_INDEX_ORDER_SCANS", "1")
+    for segments in (False, True):
+        if segments:
+            monkeypatch.setenv("PTK_SEGMENT_SCANS", "1")
         else:
-            monkeypatch.delenv("PTK_INDEX_ORDER_SCANS", raising=False)
+            monkeypatch.delenv("PTK_SEGMENT_SCANS", raising=False)
         c = ptk.Context(0)
         try:
             c.set_constants(consts)
@@ -793,3 +794,31 @@ def test_scans_by_kind_equal_scans_in_index_order(oracle, monkeypatch, name):
             c.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32))
+
+
+def test_refracting_shapes_in_the_middle_of_the_index_order(ctx, oracle):
+    """Shadow scans take the stretches between refracting shapes one after the other.  The scene
+    files put their glass last; here glass boxes and spheres sit at the front, in the middle and
+    next to each other, so that rays are bent before most shapes are tested: every plane
+    bit-identical to the correctly rounded restatement."""
+    import ptk
+    O = oracle
+    W, H = 48, 32
+    for seed in range(4):
+        c = random_pod_scene(O, 300 + seed, W, H)
+        n = c.num_shapes
+        glass = [m for m in range(50) if int(c.mats[m][5]) == 3]
+        if not glass:
+            c.mats[1][5] = 3.0
+            c.mats[1][4] = 1.5
+            glass = [1]
+        for s in (0, 1, n // 2, n - 2):                   # front, neighbours, middle, near the end
+            if 0 <= s < n:
+                c.shapes[s][1] = glass[s % len(glass)]
+        with O.variant("R"):
+            acc = O.new_accumulators(W, H)
+            _, glo, _ = O.render(c, acc, 2, 0, PIN_SEED, threads=4)
+        ctx.set_constants(c)
+        _, gglo = ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+        assert gglo == glo
+        assert _mismatch_report(ctx.read_planes(), acc, W) == ""
