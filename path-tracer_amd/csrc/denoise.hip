@@ -142,14 +142,20 @@ DEV float primary3(const float* __restrict__ p, size_t P, size_t i, const Recip&
 }
 #pragma clang fp contract(fast)
 
-// Weighted sum over N inputs with wave-uniform weights (scalar loads).
-template <int N>
-DEV float dot_w(const float (&x)[N], const __attribute__((address_space(4))) float* w)
+// Two multiply-adds in one v_pk_fma_f32: the weights of two consecutive nodes are one
+// scalar register pair, the input is the same for both halves.  Each half is an IEEE fma,
+// so the sums have the bits the one-at-a-time form gives.  An fma whose weight sits in a
+// scalar register issues at the slow rate; the packed form moves two of them at about the
+// cost of one.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) f2* W2;
+#ifndef PTK_DN_PK_FMA
+#define PTK_DN_PK_FMA 1
+#endif
+DEV f2 pk_fma(float x, f2 w, f2 a)
 {
-    float a = 0.0f;
-#pragma unroll
-    for (int i = 0; i < N; i++) a = __builtin_fmaf(x[i], w[i], a);
-    return a;
+    const f2 xx = {x, x};
+    return __builtin_elementwise_fma(xx, w, a);
 }
 
 DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
@@ -158,8 +164,10 @@ DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 // Device weight layout (built by the host from the reference's file order):
 //   [0, 350)   first layer, regrouped [channel k][group g][node]: w12[36*node + 5*g + k]
 //   [350, 360) first layer, input 35 (1/spp) per node
-//   [360, 460) second layer w23[10*node + input]
-//   [460, 530) third layer  w34[10*node + input]
+//   [360, 460) second layer, transposed: w23[10*node + input] at 360 + 10*input + node
+//   [460, 540) third layer, transposed:  w34[10*node + input] at 460 + 8*input + node
+//              (seven nodes, rows padded to eight)
+// so the weights of two consecutive nodes for one input are an aligned pair everywhere.
 //
 // 36 features + MLP for the pixel at tile coordinates (ly, lx) of an LDS tile
 // `t` of 10 planes [FR][FW]: the primaries q, then q/49 (the terms the reference
@@ -178,9 +186,10 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
                           const __attribute__((address_space(4))) float* w, float* features_out,
                           float* layers_out, size_t P, size_t idx, float (&var)[7])
 {
-    float a1[10];
+    const W2 w2 = (W2)w;               // node pairs: w2[i] = {w[2i], w[2i+1]}
+    f2 a1[5];                          // first-layer sums of nodes (2p, 2p+1)
 #pragma unroll
-    for (int nd = 0; nd < 10; nd++) a1[nd] = inv_spp * w[350 + nd];
+    for (int p = 0; p < 5; p++) a1[p] = f2{inv_spp, inv_spp} * w2[175 + p];
 
 #pragma unroll 1
     for (int k = 0; k < 5; k++) {
@@ -242,11 +251,11 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
         for (int i = 0; i < 9; i++) md += __builtin_fabsf(win[i] - mean3) * (1.0f / 9.0f);
         fk[5] = md;
 
-        const auto* wk = w + 70 * k;
+        const W2 wk = w2 + 35 * k;
 #pragma unroll
         for (int g = 0; g < 6; g++)
 #pragma unroll
-            for (int nd = 0; nd < 10; nd++) a1[nd] = __builtin_fmaf(fk[g], wk[10 * g + nd], a1[nd]);
+            for (int p = 0; p < 5; p++) a1[p] = pk_fma(fk[g], wk[5 * g + p], a1[p]);
         if (features_out) {
 #pragma unroll
             for (int g = 0; g < 6; g++) features_out[(size_t)(5 * g + k) * P + idx] = fk[g];
@@ -276,8 +285,7 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
 #pragma unroll
         for (int k = 0; k < 5; k++) {
 #pragma unroll
-            for (int nd = 0; nd < 10; nd++)
-                a1[nd] = __builtin_fmaf(mad[k], w[70 * k + 60 + nd], a1[nd]);
+            for (int p = 0; p < 5; p++) a1[p] = pk_fma(mad[k], w2[35 * k + 30 + p], a1[p]);
         }
         // one branch after all five: a conditional store per channel would split the
         // chains above into five blocks, one after the other
@@ -287,13 +295,38 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
         }
     }
 
+    // layers two and three: the sums of a node pair run over the inputs in index order,
+    // starting from zero, as a one-node dot product would
     float l2[10], l3[10];
 #pragma unroll
-    for (int nd = 0; nd < 10; nd++) l2[nd] = sigmoid(a1[nd]);
+    for (int p = 0; p < 5; p++) {
+        l2[2 * p] = sigmoid(a1[p].x);
+        l2[2 * p + 1] = sigmoid(a1[p].y);
+    }
+    f2 s3[5], s4[4];
 #pragma unroll
-    for (int nd = 0; nd < 10; nd++) l3[nd] = sigmoid(dot_w<10>(l2, w + 360 + 10 * nd));
+    for (int p = 0; p < 5; p++) s3[p] = f2{0.0f, 0.0f};
 #pragma unroll
-    for (int nd = 0; nd < 7; nd++) var[nd] = softplus(dot_w<10>(l3, w + 460 + 10 * nd));
+    for (int i = 0; i < 10; i++)
+#pragma unroll
+        for (int p = 0; p < 5; p++) s3[p] = pk_fma(l2[i], w2[180 + 5 * i + p], s3[p]);
+#pragma unroll
+    for (int p = 0; p < 5; p++) {
+        l3[2 * p] = sigmoid(s3[p].x);
+        l3[2 * p + 1] = sigmoid(s3[p].y);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) s4[p] = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) s4[p] = pk_fma(l3[i], w2[230 + 4 * i + p], s4[p]);
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        var[2 * p] = softplus(s4[p].x);
+        var[2 * p + 1] = softplus(s4[p].y);
+    }
+    var[6] = softplus(s4[3].x);
     if (layers_out) {   // layerTwoValues / layerThreeValues, kept for training
 #pragma unroll
         for (int nd = 0; nd < 10; nd++) {
@@ -301,6 +334,24 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
             layers_out[(size_t)(10 + nd) * P + idx] = l3[nd];
         }
     }
+}
+
+// The float at byte offset `byte` of a plane whose base is the same for the whole wave: the
+// base stays in scalar registers and the lane's part of the address is one 32-bit offset
+// (a frame has at most 2^28 pixels), where base + 64-bit index costs every load a 64-bit
+// multiply-add in vector registers.
+typedef __attribute__((address_space(1))) char GlobalByte;
+DEV float plane_at(const float* base, unsigned byte)
+{
+    GlobalByte* b = (GlobalByte*)(unsigned long long)base;
+    asm("" : "+s"(b));   // stays in scalar registers: the lane offset is not folded in
+    return *(const __attribute__((address_space(1))) float*)(b + byte);
+}
+DEV void plane_put(float* base, unsigned byte, float v)
+{
+    GlobalByte* b = (GlobalByte*)(unsigned long long)base;
+    asm("" : "+s"(b));
+    *(__attribute__((address_space(1))) float*)(b + byte) = v;
 }
 
 // Loads the (32+6)x(8+6) tile of primaries (and their /49 images) around
@@ -319,9 +370,9 @@ DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, in
         if (e < FPLANE) {
             int ty = e / FW, tx = e - ty * FW;
             int gy = clampi(y0 + ty - FH, H), gx = clampi(x0 + tx - FH, W);
-            size_t gi = (size_t)gy * W + gx;
+            const unsigned gb = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
 #pragma unroll
-            for (int k = 0; k < 13; k++) raw[i][k] = planes[(size_t)(PTK_PL_NORMAL + k) * P + gi];
+            for (int k = 0; k < 13; k++) raw[i][k] = plane_at(planes + (size_t)(PTK_PL_NORMAL + k) * P, gb);
         }
     }
 #pragma unroll
@@ -390,10 +441,11 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
     const int x = x0 + lx, y = y0 + ly;
     const bool inside = x < W && y < a.row_end;
     const size_t idx = inside ? (size_t)y * W + x : 0;
+    const unsigned idb = inside ? ((unsigned)y * (unsigned)W + (unsigned)x) * 4u : 0u;
     // issued before the tile load so their latency overlaps it
     float sd5[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) sd5[k] = a.planes[(size_t)(PTK_PL_SD + 1 + k) * P + idx];
+    for (int k = 0; k < 5; k++) sd5[k] = plane_at(a.planes + (size_t)(PTK_PL_SD + 1 + k) * P, idb);
 
     load_primary_tile(a.planes, P, W, H, x0, y0, n, tile);
     __syncthreads();
@@ -404,7 +456,7 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
     features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, KEEP ? a.features : nullptr,
                      KEEP ? a.layers : nullptr, P, idx, var);
 #pragma unroll
-    for (int k = 0; k < 7; k++) a.variances[(size_t)k * P + idx] = var[k];
+    for (int k = 0; k < 7; k++) plane_put(a.variances + (size_t)k * P, idb, var[k]);
 }
 
 // ---- filter ---------------------------------------------------------------
@@ -775,7 +827,6 @@ struct CentreRegs {   // stdDev[1..5] and the seven bandwidths of the pixel bein
 // address register between them.  The row base is pinned to scalar registers: otherwise the
 // compiler folds the lane offset into it and carries one 64-bit vector address per stream
 // through the row loop.
-typedef __attribute__((address_space(1))) char GlobalByte;
 DEV GlobalByte* rows_base(const void* plane0, int W, int H, int y)
 {
     // the clamp compiles to a vector min/max; back to a scalar register before the multiply

@@ -80,7 +80,7 @@ struct ptk_ctx {
     unsigned long long* rays_d = nullptr;
     double* sum_d = nullptr;
 
-    float* weights_d = nullptr;       // 530 floats
+    float* weights_d = nullptr;       // PTK_DEV_WEIGHTS floats
     float* variances_d = nullptr;     // 7 planes
     float* features_d = nullptr;      // 36 planes (allocated on demand)
     float* denoised_d = nullptr;      // 3 planes
@@ -410,7 +410,7 @@ int ptk_create(int device, ptk_ctx** out)
     if (e == hipSuccess) e = hipMalloc((void**)&c->scene_d, sizeof(DevScene));
     if (e == hipSuccess) e = hipMalloc((void**)&c->rays_d, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&c->sum_d, PTK_EXPOSURE_SUM_DOUBLES * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->weights_d, 530 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->weights_d, PTK_DEV_WEIGHTS * sizeof(float));
     // this GPU's address of the array behind ptk_auto_exposure_static, while set-up may allocate
     if (e == hipSuccess) e = ptk_exposure_static_setup(nullptr);
     if (e != hipSuccess) {
@@ -1212,14 +1212,17 @@ int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* 
     const size_t P = c->pixels;
     // device layout: first layer regrouped [channel][feature group][node] so the
     // kernel's per-channel weights are 70 consecutive floats, then the 1/spp
-    // column, then layers two and three in file order
-    float w[530];
+    // column, then layers two and three transposed ([input][node], the third layer's rows
+    // padded to eight), so the weights of two consecutive nodes are an aligned pair
+    float w[PTK_DEV_WEIGHTS] = {};
     for (int k = 0; k < 5; k++)
         for (int g = 0; g < 7; g++)
             for (int nd = 0; nd < 10; nd++) w[70 * k + 10 * g + nd] = w12[36 * nd + 5 * g + k];
     for (int nd = 0; nd < 10; nd++) w[350 + nd] = w12[36 * nd + 35];
-    std::memcpy(w + 360, w23, 100 * sizeof(float));
-    std::memcpy(w + 460, w34, 70 * sizeof(float));
+    for (int i = 0; i < 10; i++) {
+        for (int nd = 0; nd < 10; nd++) w[360 + 10 * i + nd] = w23[10 * nd + i];
+        for (int nd = 0; nd < 7; nd++) w[460 + 8 * i + nd] = w34[10 * nd + i];
+    }
     HIP_TRY(hipMemcpyAsync(c->weights_d, w, sizeof w, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // w is on this frame's stack
     if (want_features && !c->features_d)

@@ -186,9 +186,12 @@ struct PostArgs {
 };
 hipError_t ptk_launch_post_process(const PostArgs& a, hipStream_t stream);
 
+// the denoiser's weights as uploaded: first layer 360, second 100, third 10 rows of 8
+constexpr int PTK_DEV_WEIGHTS = 540;
+
 struct DenoiseArgs {
     const float* planes;
-    const float* weights;   // 530 floats: w12, w23, w34 (device)
+    const float* weights;   // PTK_DEV_WEIGHTS floats in the kernels' layout (denoise.hip), 8-byte aligned
     float* variances;       // 7 planes, plane-major (device)
     float* features;        // 36 planes, plane-major, or null
     float* layers;          // 20 planes (second- and third-layer activations), or null
