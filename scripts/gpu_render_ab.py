@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd
 import ptk
 W, H, spp = 1920, 1080, 64
 ctx = ptk.Context(0)
-for scene, feats in (("cornell_crystal", False), ("cornell", False), ("bars3", False), ("Box_Grid", False), ("MultiLightGlass", False), ("MultiLightGlass", True)):
+for scene, feats in (("cornell_crystal", False), ("cornell", False), ("bars3", False), ("Box_Grid", False), ("MultiLightGlass", False), ("MultiLightGlass", True), ("cornell_crystal", True), ("Box_Grid", True)):
     raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", scene + ".scene"), W, H, 4, 0.005, feats)
     ctx.set_constants(raw); ctx.render(4, ptk.SEED_COUNTER)
     r = []

@@ -126,6 +126,29 @@ def test_exact_mode_equals_the_rounded_libm_oracle_bit_for_bit(ctx, name):
     assert _mismatch_report(ctx.read_planes(), g["acc_8spp_R"], 64) == ""
 
 
+@pytest.mark.parametrize("name", ["MultiLightGlass", "Box_Grid", "cornell_crystal"])
+def test_one_long_launch_equals_launches_of_every_length(ctx, name):
+    """The feature sums are brought up to date every few samples inside a launch, from
+    per-sample records.  27 samples in one launch (three full batches and a remainder) must
+    leave every plane with the bits that 27 launches of one sample leave, and that launches of
+    8, 1, 9, 7 and 2 leave; the seed state and ray counts likewise."""
+    import ptk
+    g = np.load(os.path.join(GOLDEN, "render_%s_64x36.npz" % name))
+    ctx.set_math_mode(ptk.MATH_EXACT)
+    ctx.set_constants(g["constants"].tobytes())
+    rays_one, glo_one = ctx.render(27, ptk.SEED_REFERENCE, PIN_SEED)
+    one = ctx.read_planes()
+    for split in ([1] * 27, [8, 1, 9, 7, 2]):
+        ctx.reset()
+        glo, rays = PIN_SEED, 0
+        for n in split:
+            r, glo = ctx.render(n, ptk.SEED_REFERENCE, glo)
+            rays += r
+        assert ctx.sample_count == 27
+        assert glo == glo_one and rays == rays_one
+        assert _mismatch_report(ctx.read_planes(), one, 64) == ""
+
+
 def test_read_accumulators_uses_the_reference_layout(ctx):
     import ptk
     g = np.load(os.path.join(GOLDEN, "render_cornell_64x36.npz"))
