@@ -130,6 +130,24 @@ DEV float mad_procedure(float (&v)[9])
     return s.m0;
 }
 
+// The float at byte offset `byte` of a plane whose base is the same for the whole wave: the
+// base stays in scalar registers and the lane's part of the address is one 32-bit offset
+// (a frame has at most 2^28 pixels), where base + 64-bit index costs every load a 64-bit
+// multiply-add in vector registers.
+typedef __attribute__((address_space(1))) char GlobalByte;
+DEV float plane_at(const float* base, unsigned byte)
+{
+    GlobalByte* b = (GlobalByte*)(unsigned long long)base;
+    asm("" : "+s"(b));   // stays in scalar registers: the lane offset is not folded in
+    return *(const __attribute__((address_space(1))) float*)(b + byte);
+}
+DEV void plane_put(float* base, unsigned byte, float v)
+{
+    GlobalByte* b = (GlobalByte*)(unsigned long long)base;
+    asm("" : "+s"(b));
+    *(__attribute__((address_space(1))) float*)(b + byte) = v;
+}
+
 // Primary feature of one pixel (DenoiserNN.cpp:16-36): three separate
 // quotients summed in order, bit-exact.
 DEV float primary3(const float* __restrict__ p, size_t P, size_t i, const Recip& three_n)
@@ -184,7 +202,8 @@ DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 // 5 mean deviation, 6 "MAD") and channel k is 5*g + k; index 35 is 1/spp.
 DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5], float inv_spp,
                           const __attribute__((address_space(4))) float* w, float* features_out,
-                          float* layers_out, size_t P, size_t idx, float (&var)[7])
+                          float* layers_out, size_t P, unsigned idb /* pixel's byte offset */,
+                          float (&var)[7])
 {
     const W2 w2 = (W2)w;               // node pairs: w2[i] = {w[2i], w[2i+1]}
     f2 a1[5];                          // first-layer sums of nodes (2p, 2p+1)
@@ -258,10 +277,10 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
             for (int p = 0; p < 5; p++) a1[p] = pk_fma(fk[g], wk[5 * g + p], a1[p]);
         if (features_out) {
 #pragma unroll
-            for (int g = 0; g < 6; g++) features_out[(size_t)(5 * g + k) * P + idx] = fk[g];
+            for (int g = 0; g < 6; g++) plane_put(features_out + (size_t)(5 * g + k) * P, idb, fk[g]);
         }
     }
-    if (features_out) features_out[(size_t)35 * P + idx] = inv_spp;
+    if (features_out) plane_put(features_out + (size_t)35 * P, idb, inv_spp);
 
     // The "MAD" of the five channels, unrolled side by side: each is one long
     // chain of dependent compares and selects, and five independent chains in one
@@ -291,7 +310,7 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
         // chains above into five blocks, one after the other
         if (features_out) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) features_out[(size_t)(30 + k) * P + idx] = mad[k];
+            for (int k = 0; k < 5; k++) plane_put(features_out + (size_t)(30 + k) * P, idb, mad[k]);
         }
     }
 
@@ -330,28 +349,10 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
     if (layers_out) {   // layerTwoValues / layerThreeValues, kept for training
 #pragma unroll
         for (int nd = 0; nd < 10; nd++) {
-            layers_out[(size_t)nd * P + idx] = l2[nd];
-            layers_out[(size_t)(10 + nd) * P + idx] = l3[nd];
+            plane_put(layers_out + (size_t)nd * P, idb, l2[nd]);
+            plane_put(layers_out + (size_t)(10 + nd) * P, idb, l3[nd]);
         }
     }
-}
-
-// The float at byte offset `byte` of a plane whose base is the same for the whole wave: the
-// base stays in scalar registers and the lane's part of the address is one 32-bit offset
-// (a frame has at most 2^28 pixels), where base + 64-bit index costs every load a 64-bit
-// multiply-add in vector registers.
-typedef __attribute__((address_space(1))) char GlobalByte;
-DEV float plane_at(const float* base, unsigned byte)
-{
-    GlobalByte* b = (GlobalByte*)(unsigned long long)base;
-    asm("" : "+s"(b));   // stays in scalar registers: the lane offset is not folded in
-    return *(const __attribute__((address_space(1))) float*)(b + byte);
-}
-DEV void plane_put(float* base, unsigned byte, float v)
-{
-    GlobalByte* b = (GlobalByte*)(unsigned long long)base;
-    asm("" : "+s"(b));
-    *(__attribute__((address_space(1))) float*)(b + byte) = v;
 }
 
 // Loads the (32+6)x(8+6) tile of primaries (and their /49 images) around
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
     float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
     features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, KEEP ? a.features : nullptr,
-                     KEEP ? a.layers : nullptr, P, idx, var);
+                     KEEP ? a.layers : nullptr, P, idb, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) plane_put(a.variances + (size_t)k * P, idb, var[k]);
 }
@@ -478,10 +479,10 @@ DEV void load_filter_tile(const float* __restrict__ planes, size_t P, int W, int
             if (e < SS) {
                 int ty = e / SW, tx = e - ty * SW;
                 int gy = clampi(y0 + ty - N, H), gx = clampi(x0 + tx - N, W);
-                size_t gi = (size_t)gy * W + gx;
+                const unsigned gb = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
 #pragma unroll
-                for (int k = 0; k < 16; k++) raw[i][k] = planes[(size_t)k * P + gi];
-                raw[i][16] = planes[(size_t)PTK_PL_SD * P + gi];
+                for (int k = 0; k < 16; k++) raw[i][k] = plane_at(planes + (size_t)k * P, gb);
+                raw[i][16] = plane_at(planes + (size_t)PTK_PL_SD * P, gb);
             }
         }
 #pragma unroll
@@ -608,9 +609,9 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES_FILTER) void filter_kernel(Denois
     const size_t idx = inside ? (size_t)y * W + x : 0;
     float sd[6], var[7];
 #pragma unroll
-    for (int k = 0; k < 6; k++) sd[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx];
+    for (int k = 0; k < 6; k++) sd[k] = plane_at(a.planes + (size_t)(PTK_PL_SD + k) * P, (unsigned)idx * 4u);
 #pragma unroll
-    for (int k = 0; k < 7; k++) var[k] = a.variances[(size_t)k * P + idx];
+    for (int k = 0; k < 7; k++) var[k] = plane_at(a.variances + (size_t)k * P, (unsigned)idx * 4u);
 
     load_filter_tile(a.planes, P, W, H, x0, y0, N, (float)a.sample_count, ftile);
     __syncthreads();
@@ -680,9 +681,9 @@ void filter_strip_kernel(DenoiseArgs a)
         inside_next = x < W && y < a.row_end;
         idx_next = inside_next ? (size_t)y * W + x : 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) sdv_next[k] = a.planes[(size_t)(PTK_PL_SD + k) * P + idx_next];
+        for (int k = 0; k < 6; k++) sdv_next[k] = plane_at(a.planes + (size_t)(PTK_PL_SD + k) * P, (unsigned)idx_next * 4u);
 #pragma unroll
-        for (int k = 0; k < 7; k++) sdv_next[6 + k] = a.variances[(size_t)k * P + idx_next];
+        for (int k = 0; k < 7; k++) sdv_next[6 + k] = plane_at(a.variances + (size_t)k * P, (unsigned)idx_next * 4u);
 #pragma unroll
         for (int i = 0; i < EPT; i++) {
             const int e = tid + 256 * i;
