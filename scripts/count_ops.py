@@ -25,7 +25,7 @@ def main():
                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
     L.orc_render.restype = None
     table = {}
-    W, H, spp = 480, 270, 8
+    W, H, spp = 1920, 1080, 4   # the benchmark's frame size
     for scene in ("cornell", "cornell_crystal", "MultiLightGlass", "Box_Grid"):
         sc = O.load_scene(os.path.join(ROOT, "data", "scenes", scene + ".scene"))
         for feats in (False, True):
