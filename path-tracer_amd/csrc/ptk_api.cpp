@@ -270,6 +270,63 @@ void compile_shape(int type, int mat, int mat_type, const float* at, DevShape& o
     r.mat = o.mat;
 }
 
+// quat_rotate(v, q) through the quaternion-only sums of compile_shape, as the kernel's
+// quat_rotate_sums forms it: the same fp32 operations in the same order.
+void quat_rotate_sums_host(const float v[3], const float t[16], float out[3])
+{
+    const float lw = 0.0f;
+    const float vx = v[0], vy = v[1], vz = v[2];
+    float a1 = (vz + vx) * t[0];
+    float a3 = (lw - vy) * t[1];
+    float a4 = (lw + vy) * t[2];
+    float a2 = a1 + a3 + a4;
+    float a5 = (vz - vx) * t[3];
+    a5 = (a5 + a2) / 2.0f;
+    const float pw = a5 - a1 + (vz - vy) * t[4];
+    const float px = a5 - a2 + (vx + lw) * t[5];
+    const float py = a5 - a3 + (lw - vx) * t[6];
+    const float pz = a5 - a4 + (vz + vy) * t[7];
+    float b1 = t[8] * (px + py);
+    float b3 = t[9] * (pw + pz);
+    float b4 = t[10] * (pw - pz);
+    float b2 = b1 + b3 + b4;
+    float b5 = t[11] * (px - py);
+    b5 = (b5 + b2) / 2.0f;
+    out[0] = b5 - b2 + t[13] * (px + pw);
+    out[1] = b5 - b3 + t[14] * (py + pz);
+    out[2] = b5 - b4 + t[15] * (pw - px);
+}
+
+// DevScene::cam_kind: the scan records as a ray from the camera position meets them.
+void compile_camera_records(DevScene& d)
+{
+    const float* o = d.cam_pos;
+    for (int k = 0; k < d.num_shapes; k++) {
+        const ScanRec& r = d.scan_kind[k];
+        ScanRec& q = d.cam_kind[k];
+        q = r;
+        if (r.type == 1) {
+            float rp[3];
+            if (r.rotated) {
+                const float rel[3] = {o[0] - r.c[0], o[1] - r.c[1], o[2] - r.c[2]};
+                quat_rotate_sums_host(rel, d.rot[r.index], rp);
+                for (int i = 0; i < 3; i++) rp[i] = rp[i] + r.c[i];
+            } else {
+                for (int i = 0; i < 3; i++) rp[i] = (o[i] - r.c[i]) + r.c[i];
+            }
+            for (int i = 0; i < 3; i++) {
+                q.c[i] = rp[i];
+                q.lo[i] = r.lo[i] - rp[i];
+                q.hi[i] = r.hi[i] - rp[i];
+            }
+        } else {
+            const float l[3] = {r.c[0] - o[0], r.c[1] - o[1], r.c[2] - o[2]};
+            for (int i = 0; i < 3; i++) q.c[i] = l[i];
+            q.lo[0] = l[0] * l[0] + l[1] * l[1] + l[2] * l[2];
+        }
+    }
+}
+
 int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
 {
     if (k.res_h <= 0 || k.res_v <= 0 || (int64_t)k.res_h * k.res_v > (int64_t)1 << 28)
@@ -361,6 +418,7 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
         }
         s0 = s1 + 1;
     }
+    compile_camera_records(d);
     return PTK_OK;
 }
 
@@ -866,10 +924,15 @@ int ptk_set_camera(ptk_ctx* c, const float* pos, const float* fwd, const float* 
         c->host_scene.cam_right[i] = right[i];
         c->host_scene.cam_up[i] = up[i];
     }
-    // the four vectors lead the structure
+    if (!c->big_scene) compile_camera_records(c->host_scene);
+    // the four vectors lead the structure; the records formed from the position end it
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpyAsync(c->scene_d, &c->host_scene, offsetof(DevScene, rand_samp),
                            hipMemcpyHostToDevice, c->stream));
+    if (!c->big_scene)
+        HIP_TRY(hipMemcpyAsync((char*)c->scene_d + offsetof(DevScene, cam_kind),
+                               c->host_scene.cam_kind, sizeof c->host_scene.cam_kind,
+                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ptk_reset_accumulators(c);
 }

@@ -71,6 +71,13 @@ struct DevScene {
     // may when no shape refracts (any_dielectric == 0), because then its order does not matter.
     ScanRec scan_kind[PTK_MAX_SHAPES + 1];
     int32_t n_plain, n_rotated, n_spheres, any_dielectric;
+    // The records of scan_kind once more, for rays that leave the camera: every such ray has
+    // the same origin, so what a shape test forms from the origin and the shape alone is the
+    // same for every lane and every sample, and the host forms it once with the kernel's fp32
+    // operations in the kernel's order.  Boxes: c = the origin in the box's frame ((o - c) + c,
+    // rotated first for a rotated box), lo / hi = the slab numerators lo - c' and hi - c'.
+    // Spheres: c = centre - origin, lo[0] = its squared length.  Everything else as scan_kind.
+    ScanRec cam_kind[PTK_MAX_SHAPES + 1];
     // For shadow scans of scenes WITH refracting shapes: a refracting shape bends the ray for
     // the shapes after it, so the order is free only between two of them.  scan_seg holds, for
     // each stretch of the index order that ends at a refracting shape (or at the last shape),
