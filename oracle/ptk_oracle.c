@@ -244,17 +244,19 @@ static void box_normal(const float* a, const float* obb_hit, const float* dir,
     const float* lo = a + 3;
     const float* hi = a + 6;
     float thr = shadow_variant ? 0.0f : EPS;
-    OPS(8); /* on average four |a-b| tests before a face matches */
+    /* one |a - b| < EPS test: a subtraction and a comparison, counted when it is made */
+#define NEAR(x, y) (OPS(2), fabsf((x) - (y)) < EPS)
     n[0] = n[1] = n[2] = 0.0f;
-    if (fabsf(lo[0] - hi[0]) < EPS)      n[0] = dir[0] > thr ? -1 : 1;
-    else if (fabsf(lo[1] - hi[1]) < EPS) n[1] = dir[1] > thr ? -1 : 1;
-    else if (fabsf(lo[2] - hi[2]) < EPS) n[2] = dir[2] > thr ? -1 : 1;
-    else if (fabsf(obb_hit[0] - lo[0]) < EPS) n[0] = -1;
-    else if (fabsf(obb_hit[0] - hi[0]) < EPS) n[0] = 1;
-    else if (fabsf(obb_hit[1] - lo[1]) < EPS) n[1] = -1;
-    else if (fabsf(obb_hit[1] - hi[1]) < EPS) n[1] = 1;
-    else if (fabsf(obb_hit[2] - (shadow_variant ? lo[0] : lo[2])) < EPS) n[2] = -1;
-    else if (fabsf(obb_hit[2] - (shadow_variant ? hi[0] : hi[2])) < EPS) n[2] = 1;
+    if (NEAR(lo[0], hi[0]))      n[0] = dir[0] > thr ? -1 : 1;
+    else if (NEAR(lo[1], hi[1])) n[1] = dir[1] > thr ? -1 : 1;
+    else if (NEAR(lo[2], hi[2])) n[2] = dir[2] > thr ? -1 : 1;
+    else if (NEAR(obb_hit[0], lo[0])) n[0] = -1;
+    else if (NEAR(obb_hit[0], hi[0])) n[0] = 1;
+    else if (NEAR(obb_hit[1], lo[1])) n[1] = -1;
+    else if (NEAR(obb_hit[1], hi[1])) n[1] = 1;
+    else if (NEAR(obb_hit[2], shadow_variant ? lo[0] : lo[2])) n[2] = -1;
+    else if (NEAR(obb_hit[2], shadow_variant ? hi[0] : hi[2])) n[2] = 1;
+#undef NEAR
     float qc[4] = {a[9], -a[10], -a[11], -a[12]};
     quat_rotate(n, qc);
     normalize3(n);
