@@ -365,6 +365,16 @@ int compile_scene(const ptk_constants& k, int want_features, DevScene& d)
         d.imp[i] = (int)k.important_shapes[i];
     }
     std::memcpy(d.mats, k.mat_list, sizeof d.mats);
+    for (int m = 0; m < PTK_MAX_MATS; m++) {   // Renderers.cpp:330-346, per side of the surface
+        const float eta_in = 1.0f / d.mats[m][4];
+        const float eta_out = 1.0f / eta_in;
+        float r_in = (1.0f - eta_in) / (1.0f + eta_in);
+        float r_out = (1.0f - eta_out) / (1.0f + eta_out);
+        d.mat_glass[m][0] = eta_in;
+        d.mat_glass[m][1] = eta_out;
+        d.mat_glass[m][2] = r_in * r_in;
+        d.mat_glass[m][3] = r_out * r_out;
+    }
 
     for (int s = 0; s < k.num_shapes; s++) {
         int type = k.shapes[s][0], mat = k.shapes[s][1], a = k.shapes[s][2];

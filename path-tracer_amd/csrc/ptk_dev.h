@@ -54,6 +54,10 @@ struct DevScene {
     int32_t ordered_boxes;   // every box has lo <= hi on every axis (the merged slab test needs it)
     DevShape shape[PTK_MAX_SHAPES];
     float mats[PTK_MAX_MATS][6];
+    // Per material, what the dielectric branch derives from the refractive index alone, formed
+    // on the host by the kernel's fp32 operations: eta entering (1 / index), eta leaving
+    // (1 / that), and the Schlick term ((1 - eta) / (1 + eta))^2 of each.
+    float mat_glass[PTK_MAX_MATS][4];
     // Per shape, the sixteen sums of quaternion components that the two
     // quaternion products of a world-to-box rotation form from the box's
     // quaternion alone (same fp32 additions, done once on the host): [0..7] for
