@@ -35,6 +35,8 @@ constexpr int FW = TW + 2 * FH;        // 38
 constexpr int FR = TH + 2 * FH;        // 14
 constexpr int FPLANE = FW * FR;        // 532 words per feature plane
 constexpr int PTILE_FLOATS = 10 * FPLANE;   // primaries and primaries / 49
+constexpr int CW = FW;                 // columns of a column-statistics plane
+constexpr int CPLANE = CW * TH;        // 304 words: one entry per tile column and output row
 #ifndef PTK_DN_LDS_PAD
 #define PTK_DN_LDS_PAD 0               // measurement builds: unused LDS words, to lower occupancy
 #endif
@@ -200,10 +202,18 @@ DEV float softplus(float x) { return fast_log(1.0f + fast_exp(x)); }
 // index order; the MLP is compared within a tolerance either way).
 // Feature index of group g (0 value, 1 sd, 2 mean7, 3 sd7, 4 gradient,
 // 5 mean deviation, 6 "MAD") and channel k is 5*g + k; index 35 is 1/spp.
-DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5], float inv_spp,
-                          const __attribute__((address_space(4))) float* w, float* features_out,
-                          float* layers_out, size_t P, unsigned idb /* pixel's byte offset */,
-                          float (&var)[7])
+//
+// FAST is the tolerance-held form (ptk_denoise variant 2): the discrete parts (primaries,
+// "median getter") are the same instructions on the same values, the smooth statistics are
+// formed a cheaper way -- the 7x7 mean and deviation from per-column statistics shared
+// through LDS (`cs`, see column_stats), the Sobel magnitude from symmetric partial sums, roots
+// from the hardware instruction -- and agree with the other form to a few ulp of the
+// channel's magnitude.  `t` then holds the five primaries only.
+template <bool FAST>
+DEV void features_and_mlp(const float* t, const float* cs, int ly, int lx, const float (&sd5)[5],
+                          float inv_spp, const __attribute__((address_space(4))) float* w,
+                          float* features_out, float* layers_out, size_t P,
+                          unsigned idb /* pixel's byte offset */, float (&var)[7])
 {
     const W2 w2 = (W2)w;               // node pairs: w2[i] = {w[2i], w[2i+1]}
     f2 a1[5];                          // first-layer sums of nodes (2p, 2p+1)
@@ -213,34 +223,56 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
 #pragma unroll 1
     for (int k = 0; k < 5; k++) {
         const float* tk = t + k * FPLANE + ly * FW + lx;   // window origin (top-left of 7x7)
-        const float* tk49 = tk + 5 * FPLANE;
         float fk[7];
         fk[0] = tk[FH * FW + FH];
         fk[1] = k == 0 ? sd5[0] : k == 1 ? sd5[1] : k == 2 ? sd5[2] : k == 3 ? sd5[3] : sd5[4];
 
-        // 7x7 mean: the reference adds q/49 term by term in row-major order
         float mean7 = 0.0f;
         float ss = 0.0f;
-#if PTK_DN_ABLATE & 2
-        mean7 = tk49[0]; ss = tk[0];             // measurement build: no 7x7 statistics
-#else
+        if (FAST) {
+            // The window's seven columns each bring their mean c_i and their squared deviations
+            // about it, S_i (column_stats).  Window mean = mean of the c_i; squared deviations
+            // about it = sum of S_i + 7 * sum of (c_i - mean)^2, an identity in which every
+            // square is of a centred quantity, so nothing cancels.
+            const float* ck = cs + (2 * k) * CPLANE + ly * CW + lx;
+            float c[7];
 #pragma unroll
-        for (int j = 0; j < 7; j++)
-#pragma unroll
-            for (int i = 0; i < 7; i++) mean7 += tk49[j * FW + i];
-        // 7x7 standard deviation about that mean
-#pragma unroll
-        for (int j = 0; j < 7; j++)
+            for (int i = 0; i < 7; i++) c[i] = ck[i];
+            mean7 = (((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + c[6])) * (1.0f / 7.0f);
+            const float* sk = ck + CPLANE;
+            float within = ((sk[0] + sk[1]) + (sk[2] + sk[3])) + ((sk[4] + sk[5]) + sk[6]);
+            float between = 0.0f;
 #pragma unroll
             for (int i = 0; i < 7; i++) {
-                float d = tk[j * FW + i] - mean7;
-                ss = __builtin_fmaf(d, d, ss);
+                float d = c[i] - mean7;
+                between = __builtin_fmaf(d, d, between);
             }
+            ss = __builtin_fmaf(7.0f, between, within);
+            fk[3] = __builtin_amdgcn_sqrtf(ss * (1.0f / 49.0f));
+        } else {
+            const float* tk49 = tk + 5 * FPLANE;
+#if PTK_DN_ABLATE & 2
+            mean7 = tk49[0]; ss = tk[0];             // measurement build: no 7x7 statistics
+#else
+            // 7x7 mean: the reference adds q/49 term by term in row-major order
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+#pragma unroll
+                for (int i = 0; i < 7; i++) mean7 += tk49[j * FW + i];
+            // 7x7 standard deviation about that mean
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    float d = tk[j * FW + i] - mean7;
+                    ss = __builtin_fmaf(d, d, ss);
+                }
 #endif
+            // the compiler's root without its rescaling of arguments below 2^-96 (exact_ops.h):
+            // the same bits above that, and this feature is compared within a tolerance
+            fk[3] = ptk_exact::exact_sqrt_unscaled(ss * (1.0f / 49.0f));
+        }
         fk[2] = mean7;
-        // the compiler's root without its rescaling of arguments below 2^-96 (exact_ops.h):
-        // the same bits above that, and this feature is compared within a tolerance
-        fk[3] = ptk_exact::exact_sqrt_unscaled(ss * (1.0f / 49.0f));
 
         float win[9];
         float mean3 = 0.0f;
@@ -253,7 +285,15 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
                 mean3 += tk[o];
             }
         mean3 *= 1.0f / 9.0f;
-        {
+        if (FAST) {
+            // each gradient as the difference of two three-tap sums formed the same way, so a
+            // flat window gives exactly zero
+            const float gx = (__builtin_fmaf(2.0f, win[1], win[0]) + win[2]) -
+                             (__builtin_fmaf(2.0f, win[7], win[6]) + win[8]);
+            const float gy = (__builtin_fmaf(2.0f, win[3], win[0]) + win[6]) -
+                             (__builtin_fmaf(2.0f, win[5], win[2]) + win[8]);
+            fk[4] = __builtin_amdgcn_sqrtf(__builtin_fmaf(gx, gx, gy * gy));
+        } else {
 #pragma clang fp contract(off)
             // Sobel sums in the reference's accumulation order; zero taps add +-0
             float gx = 0.0f, gy = 0.0f;
@@ -358,6 +398,7 @@ DEV void features_and_mlp(const float* t, int ly, int lx, const float (&sd5)[5],
 // Loads the (32+6)x(8+6) tile of primaries (and their /49 images) around
 // the block's outputs.  All of a thread's global loads are issued before the
 // first quotient is formed, so the tile costs one memory latency, not three.
+template <bool WITH49>
 DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, int H, int x0, int y0,
                            float n, float* t)
 {
@@ -394,7 +435,7 @@ DEV void load_primary_tile(const float* __restrict__ planes, size_t P, int W, in
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 t[k * FPLANE + e] = q[k];
-                t[(5 + k) * FPLANE + e] = div_by(q[k], r49);
+                if (WITH49) t[(5 + k) * FPLANE + e] = div_by(q[k], r49);
             }
         }
     }
@@ -448,14 +489,76 @@ __global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_kernel(Denoise
 #pragma unroll
     for (int k = 0; k < 5; k++) sd5[k] = plane_at(a.planes + (size_t)(PTK_PL_SD + 1 + k) * P, idb);
 
-    load_primary_tile(a.planes, P, W, H, x0, y0, n, tile);
+    load_primary_tile<true>(a.planes, P, W, H, x0, y0, n, tile);
     __syncthreads();
     if (!inside) return;
 
     float var[7];
     const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
-    features_and_mlp(tile, ly, lx, sd5, 1.0f / n, w, KEEP ? a.features : nullptr,
-                     KEEP ? a.layers : nullptr, P, idb, var);
+    features_and_mlp<false>(tile, nullptr, ly, lx, sd5, 1.0f / n, w, KEEP ? a.features : nullptr,
+                            KEEP ? a.layers : nullptr, P, idb, var);
+#pragma unroll
+    for (int k = 0; k < 7; k++) plane_put(a.variances + (size_t)k * P, idb, var[k]);
+}
+
+// Per-column statistics of the tile for the 7x7 window of the tolerance-held form: for each
+// of the tile's 38 columns and each of its 8 output rows y, the mean c of the column's seven
+// values in rows y-3 .. y+3 and the sum S of their squared deviations from c, for the five
+// channels.  Element e = row * CW + column of a statistics plane belongs to tile element e
+// of the window's top row (CW == FW), so consecutive threads read and write consecutive words.
+// Layout: plane 2k holds c of channel k, plane 2k + 1 holds S.
+DEV void column_stats(const float* t, float* cs)
+{
+    for (int e = threadIdx.x; e < CPLANE; e += 256) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float* p = t + k * FPLANE + e;
+            float q[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) q[j] = p[j * FW];
+            const float c = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + q[6])) * (1.0f / 7.0f);
+            float s2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const float d = q[j] - c;
+                s2 = __builtin_fmaf(d, d, s2);
+            }
+            cs[(2 * k) * CPLANE + e] = c;
+            cs[(2 * k + 1) * CPLANE + e] = s2;
+        }
+    }
+}
+
+// The tolerance-held form of the pass (ptk_denoise variant 2): primaries and the "median
+// getter" as above, bit for bit; 7x7 mean and deviation from shared column statistics.
+template <bool KEEP>
+__global__ __launch_bounds__(256, PTK_DN_WAVES) void features_mlp_fast_kernel(DenoiseArgs a)
+{
+    __shared__ float tile[5 * FPLANE];
+    __shared__ float cstat[10 * CPLANE];
+    const int W = a.width, H = a.height;
+    const size_t P = (size_t)W * H;
+    const float n = (float)a.sample_count;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    int x0, y0;
+    if (!tile_origin(a, x0, y0)) return;   // uniform over the workgroup, before any barrier
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = x < W && y < a.row_end;
+    const unsigned idb = inside ? ((unsigned)y * (unsigned)W + (unsigned)x) * 4u : 0u;
+    float sd5[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) sd5[k] = plane_at(a.planes + (size_t)(PTK_PL_SD + 1 + k) * P, idb);
+
+    load_primary_tile<false>(a.planes, P, W, H, x0, y0, n, tile);
+    __syncthreads();
+    column_stats(tile, cstat);
+    __syncthreads();
+    if (!inside) return;
+
+    float var[7];
+    const auto* w = (const __attribute__((address_space(4))) float*)a.weights;
+    features_and_mlp<true>(tile, cstat, ly, lx, sd5, 1.0f / n, w, KEEP ? a.features : nullptr,
+                           KEEP ? a.layers : nullptr, P, idb, var);
 #pragma unroll
     for (int k = 0; k < 7; k++) plane_put(a.variances + (size_t)k * P, idb, var[k]);
 }
@@ -1087,10 +1190,15 @@ hipError_t launch_strip(K kernel, const DenoiseArgs& a, size_t lds, int per_cu, 
 #ifndef PTK_DN_STRIP_PER_CU
 #define PTK_DN_STRIP_PER_CU 3
 #endif
-hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream)
+hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream, bool fast)
 {
     dim3 grid(denoise_grid(a));
-    if (a.features || a.layers)
+    const bool keep = a.features || a.layers;
+    if (fast && keep)
+        hipLaunchKernelGGL(features_mlp_fast_kernel<true>, grid, dim3(256), 0, stream, a);
+    else if (fast)
+        hipLaunchKernelGGL(features_mlp_fast_kernel<false>, grid, dim3(256), 0, stream, a);
+    else if (keep)
         hipLaunchKernelGGL(features_mlp_kernel<true>, grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(features_mlp_kernel<false>, grid, dim3(256), 0, stream, a);

@@ -1278,9 +1278,10 @@ int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* 
         return fail(PTK_ERR_STATE, "ptk_denoise: the feature planes were not accumulated (render "
                     "with want_denoise_features, or write planes 3..37)");
     if (n < 0 || n > 8) return fail(PTK_ERR_ARG, "ptk_denoise: N %d outside [0,8]", n);
-    if (variant != 0 && variant != 1)
+    if (variant < 0 || variant > 2)
         return fail(PTK_ERR_ARG, "ptk_denoise: variant %d (0: the denoiser; 1: the same with the "
-                    "filter on LDS tiles at N = 1 as well)", variant);
+                    "filter on LDS tiles at N = 1 as well; 2: the feature pass in its "
+                    "tolerance-held form)", variant);
     if (row_begin < 0 || row_end > c->height || row_begin > row_end)
         return fail(PTK_ERR_ARG, "ptk_denoise: rows [%d,%d) outside [0,%d)", row_begin, row_end,
                     c->height);
@@ -1332,7 +1333,7 @@ int denoise_device(ptk_ctx* c, const float* w12, const float* w23, const float* 
     c->have_denoised = false;   // until the launches below are queued
     // both launches are queued back to back and the host waits once, after the second
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(ptk_launch_features_mlp(a, c->stream));
+    HIP_TRY(ptk_launch_features_mlp(a, c->stream, variant == 2));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     HIP_TRY(ptk_launch_filter(a, c->stream, variant == 1));
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));

@@ -213,7 +213,9 @@ struct DenoiseArgs {
     int32_t n;              // filter half-width
     int32_t row_begin, row_end;  // rows [row_begin, row_end) are produced (a band, or the image)
 };
-hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream);
+// fast: the tolerance-held form of the pass (smooth statistics formed a cheaper way; the
+// discrete ones unchanged).
+hipError_t ptk_launch_features_mlp(const DenoiseArgs& a, hipStream_t stream, bool fast = false);
 
 // One training step's reductions (DenoiserNN::GenRelMSE and CPUBackProp,
 // DenoiserNN.cpp:959-1103, 1461-1474).  sums (device, PTK_TRAIN_SUM_DOUBLES

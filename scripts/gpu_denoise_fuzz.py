@@ -4,7 +4,9 @@ strip and wave widths), every filter half-width 0..8, every weight file, sample 
 and are not powers of two, and value classes the rendered frames do not reach (exact zeros,
 constant planes, large magnitudes, tiny deviations).  Discrete feature planes must be equal bit
 for bit; smooth ones, bandwidths, filtered colour and weight sums within the tolerances of
-tests/test_gpu_parity.py.  Usage: gpu_denoise_fuzz.py [cases] [seed]"""
+tests/test_gpu_parity.py.  With variant 2 (the tolerance-held feature pass) the 7x7 mean and the
+Sobel magnitude are compared within a tolerance as well; primaries, per-pixel deviations, the
+"median getter" and 1/spp stay bit for bit.  Usage: gpu_denoise_fuzz.py [cases] [seed] [variant]"""
 import glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
@@ -51,8 +53,12 @@ def random_planes(rng, W, H, spp, kind):
     return pl.astype(np.float32)
 
 
-def fuzz(cases, seed, ctx=None, verbose=True):
+def fuzz(cases, seed, ctx=None, verbose=True, variant=0):
     """Runs `cases` cases; returns the descriptions of those with differences."""
+    exact = ((0, 15), (20, 25), (30, 36)) if variant != 2 else ((0, 10), (30, 36))
+    smooth = [("sd7", 15, 20, 2e-5), ("meandev", 25, 30, 2e-5)]
+    if variant == 2:
+        smooth += [("mean7", 10, 15, 2e-6), ("sobel", 20, 25, 2e-5)]
     rng = np.random.default_rng(seed)
     weight_files = sorted(glob.glob(os.path.join(ROOT, "data", "weights", "*.txt")))
     fixed = [(1, 1), (1, 9), (9, 1), (2, 2), (3, 5), (6, 6), (7, 7), (8, 8), (31, 9), (32, 8), (33, 9),
@@ -78,18 +84,18 @@ def fuzz(cases, seed, ctx=None, verbose=True):
         msgs = []
         for n in ([1] + [int(x) for x in rng.choice([0, 2, 3, 4, 5, 6, 7, 8], 2, replace=False)]):
             den, wc = O.filter(pl, var, W, H, spp, n, threads=8)
-            r = ctx.denoise(w, n, 0, want_features=True)
+            r = ctx.denoise(w, n, variant, want_features=True)
             f = r["features"]
-            for lo, hi in ((0, 15), (20, 25), (30, 36)):
+            for lo, hi in exact:
                 if not same(f[:, lo:hi], feats[:, lo:hi]).all():
                     msgs.append("N=%d features %d..%d differ in %d words" % (
                         n, lo, hi, int((~same(f[:, lo:hi], feats[:, lo:hi])).sum())))
-            for name, got, want, tol in (("sd7", f[:, 15:20], feats[:, 15:20], 2e-5),
-                                         ("meandev", f[:, 25:30], feats[:, 25:30], 2e-5),
-                                         ("variances", r["variances"], var, 2e-5),
-                                         ("denoised", r["denoised"], den, 5e-5),
-                                         ("wcSum", r["wcSum"], wc, 5e-5)):
-                ok = rel_ok(got, want, tol, floor if name in ("meandev", "denoised", "wcSum") else 1e-7)
+            checks = [(nm, f[:, lo:hi], feats[:, lo:hi], tol) for nm, lo, hi, tol in smooth]
+            checks += [("variances", r["variances"], var, 2e-5), ("denoised", r["denoised"], den, 5e-5),
+                       ("wcSum", r["wcSum"], wc, 5e-5)]
+            floored = ("meandev", "denoised", "wcSum") + (("sd7", "mean7", "sobel") if variant == 2 else ())
+            for name, got, want, tol in checks:
+                ok = rel_ok(got, want, tol, floor if name in floored else 1e-7)
                 if not ok.all():
                     j = np.argwhere(~ok)[0]
                     msgs.append("N=%d %s: %d outside %g, first at %s: %r vs %r" % (
@@ -106,7 +112,8 @@ def fuzz(cases, seed, ctx=None, verbose=True):
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    bad = fuzz(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+    bad = fuzz(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 11,
+               variant=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     print("%d cases, %d with differences" % (cases, len(bad)))
     return 1 if bad else 0
 

@@ -33,7 +33,7 @@ def main():
         ctx.write_planes(synthetic(W, H), 128)
     w = ptk.load_weights(os.path.join(ROOT, "data", "weights", "BEST.txt"))
     for N in (1, 3):
-        for variant in (0,):
+        for variant in ((0, 2) if N == 1 else (0,)):
             ts = []
             for _ in range(reps):
                 ctx.denoise(w, N, variant, want_outputs=False)
