@@ -273,8 +273,14 @@ int ptk_auto_exposure_static(const float* colour_planes_d, size_t pixels, int wi
  * variant 0 is the denoiser (a feature + MLP kernel, then a filter kernel: for
  * N = 1 on a register window of rows, for wider windows on LDS tiles).  variant 1
  * forces the LDS-tile filter at N = 1 too: same arithmetic, same bits, slower; it
- * exists so that the two forms can be checked against each other.  Anything else
- * is PTK_ERR_ARG.
+ * exists so that the two forms can be checked against each other.  variant 2 runs
+ * the feature pass in its tolerance-held form: primaries, per-pixel deviations, the
+ * "median getter" statistic and 1/spp as in variant 0, bit for bit; the 7x7 mean
+ * and deviation (from per-column statistics shared between the seven pixels of a
+ * row that use them), the Sobel magnitude and the square roots formed a cheaper
+ * way, within a few ulp of the channel's magnitude of variant 0's; bandwidths,
+ * filtered colour and weight sum within 2e-5 relative.  A quarter faster.
+ * Anything else is PTK_ERR_ARG.
  * Outputs (all optional): denoised rgb interleaved (3P), wcSum (P),
  * variances (7P, pixel-major), features (36P, pixel-major). */
 int ptk_denoise(ptk_ctx* ctx, const float w12[360], const float w23[100], const float w34[70],

@@ -29,16 +29,22 @@ struct Network {
     using M = typename O::Mask;
 
     // One general pass-1 step on slots (m0..m4).
+    //
+    // In pass 1 the slots m1 <= m2 <= m3 <= m4 stay in ascending order: they start equal, a
+    // step that stops at k >= 2 stores a v with m[k-1] < v <= m[k] into m[k-1], a step that
+    // stops at 1 writes m0 only, and a step that never stops sets m1..m3 to the old m4 and m4
+    // to a larger v.  (A NaN never enters them: v > m[k] is false for it, so it stops at 1.)
+    // Hence v > m[k] implies v > m[j] for every j < k, "the scan reached k" is just
+    // v > m[k-1], and the conjunctions of the literal scan drop out.
     static PTK_MAD_FN void pass1_step(float v, float& m0, float& m1, float& m2, float& m3, float& m4)
     {
         const M g1 = O::gt(v, m1), g2 = O::gt(v, m2), g3 = O::gt(v, m3), g4 = O::gt(v, m4);
-        const M a2 = O::land(g1, g2), a3 = O::land(a2, g3), a4 = O::land(a3, g4);
-        const float t = O::sel(a4, m4, v);                         // what a written slot receives
-        const float n4 = O::sel(a4, v, m4);
-        m0 = O::sel(O::lor(a4, O::lnot(g1)), t, m0);               // stopped at 1, or shifted
-        m1 = O::sel(O::lor(a4, O::andn(g1, g2)), t, m1);           // stopped at 2, or shifted
-        m2 = O::sel(O::lor(a4, O::andn(a2, g3)), t, m2);
-        m3 = O::sel(O::lor(a4, O::andn(a3, g4)), t, m3);
+        const float t = O::sel(g4, m4, v);                         // what a written slot receives
+        const float n4 = O::sel(g4, v, m4);
+        m0 = O::sel(O::lor(g4, O::lnot(g1)), t, m0);               // stopped at 1, or shifted
+        m1 = O::sel(O::lor(g4, O::andn(g1, g2)), t, m1);           // stopped at 2, or shifted
+        m2 = O::sel(O::lor(g4, O::andn(g2, g3)), t, m2);
+        m3 = O::sel(g3, t, m3);                                    // stopped at 4, or shifted
         m4 = n4;
     }
 
@@ -66,10 +72,9 @@ struct Network {
         for (int i = 2; i < 8; i++) pass1_step(v[i], m0, m1, m2, m3, m4);
         {   // last step: only m[0] is read afterwards
             const float x = v[8];
-            const M g1 = O::gt(x, m1), g2 = O::gt(x, m2), g3 = O::gt(x, m3), g4 = O::gt(x, m4);
-            const M a4 = O::land(O::land(O::land(g1, g2), g3), g4);
-            const float t = O::sel(a4, m4, x);
-            m0 = O::sel(O::lor(a4, O::lnot(g1)), t, m0);
+            const M g1 = O::gt(x, m1), g4 = O::gt(x, m4);      // ascending slots: see pass1_step
+            const float t = O::sel(g4, m4, x);
+            m0 = O::sel(O::lor(g4, O::lnot(g1)), t, m0);
         }
         return m0;
     }

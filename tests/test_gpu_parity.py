@@ -207,7 +207,7 @@ def test_denoiser_odd_sizes_and_edges(ctx, oracle):
         assert _rel_ok(r["wcSum"], wc, 5e-5).all()
     import ptk
     with pytest.raises(ptk.PtkError, match="variant"):
-        ctx.denoise(w, 1, 2)            # only variants 0 and 1 exist
+        ctx.denoise(w, 1, 3)            # only variants 0, 1 and 2 exist
 
 
 @pytest.mark.gpu
