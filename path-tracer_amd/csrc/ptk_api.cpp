@@ -78,6 +78,8 @@ struct ptk_ctx {
     size_t seed_chunk_bytes = SEED_CHUNK_BYTES;
     bool segment_scans_only = false;  // PTK_SEGMENT_SCANS=1: the kernels with the bending code for every scene (tests)
     unsigned long long* rays_d = nullptr;
+    unsigned* sched_d = nullptr;      // path-trace work items: 1 + (16x16-pixel tiles of the image) words
+    int render_chunk_spp = 0;         // PTK_RENDER_CHUNK_SPP: samples per work item (0: the launcher chooses)
     double* sum_d = nullptr;
 
     float* weights_d = nullptr;       // PTK_DEV_WEIGHTS floats
@@ -112,6 +114,7 @@ int bind(ptk_ctx* c)
 void free_image_buffers(ptk_ctx* c)
 {
     (void)hipFree(c->planes_d); c->planes_d = nullptr;
+    (void)hipFree(c->sched_d); c->sched_d = nullptr;
     (void)hipFree(c->seeds_d); c->seeds_d = nullptr;
     if (c->seeds_h) (void)hipHostFree(c->seeds_h);
     c->seeds_h = nullptr;
@@ -155,6 +158,8 @@ int ensure_image(ptk_ctx* c, int width, int height)
     if (e == hipSuccess) e = hipMalloc((void**)&c->variances_d, 7 * P * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&c->denoised_d, 3 * P * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&c->wcsum_d, P * sizeof(float));
+    const size_t tiles = (size_t)((width + 15) / 16) * (size_t)((height + 15) / 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->sched_d, (1 + tiles) * sizeof(unsigned));
     if (e != hipSuccess) {
         free_image_buffers(c);
         c->width = c->height = 0;
@@ -468,6 +473,10 @@ int ptk_create(int device, ptk_ctx** out)
     c->device = device;
     std::memset(&c->times, 0, sizeof c->times);
     if (const char* v = std::getenv("PTK_SEGMENT_SCANS")) c->segment_scans_only = v[0] == '1';
+    if (const char* v = std::getenv("PTK_RENDER_CHUNK_SPP")) {
+        const long n = std::strtol(v, nullptr, 10);
+        if (n >= 1 && n <= 0x7fffffff) c->render_chunk_spp = (int)n;
+    }
     if (const char* v = std::getenv("PTK_SEED_CHUNK_BYTES")) {
         const unsigned long long b = std::strtoull(v, nullptr, 10);
         if (b >= 16) c->seed_chunk_bytes = (size_t)b;
@@ -996,6 +1005,9 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     a.scene = c->scene_d;
     a.planes = c->planes_d;
     a.rays = c->rays_d;
+    a.sched = c->sched_d;
+    a.chunk_spp = c->render_chunk_spp;
+    a.n_chunks = a.n_items = a.tiles_x = a.tiles_y = 0;   // the launcher's
     a.stream_id = c->stream_id;
     a.width = c->width;
     a.height = c->height;

@@ -144,6 +144,13 @@ struct RenderArgs {
     // for pixel p is at seeds[(s * seed_stride + p - seed_pixel0) * 2].
     int32_t row_begin, row_end;
     int64_t seed_pixel0, seed_stride;
+    // Work items of a launch (filled by the launcher, except sched and chunk_spp): the band's
+    // 16x16-pixel tiles times the chunks of chunk_spp samples the launch's spp are cut into.
+    // sched: device memory, 1 + tiles words: [0] the next item to hand out, [1 + t] the chunks
+    // of tile t that are finished; zeroed by the launcher.  chunk_spp on entry: 0 = the
+    // launcher chooses, otherwise the chunk length to use.
+    unsigned* sched;
+    int32_t chunk_spp, n_chunks, n_items, tiles_x, tiles_y;
     BigScene big;            // ptk_set_scene scenes only (render_bvh_*.hip)
 };
 

@@ -782,6 +782,47 @@ def test_reference_seeds_staged_in_row_bands_give_the_same_frame(oracle, monkeyp
     assert _same(results[1][1][2], acc).all()
 
 
+@pytest.mark.parametrize("name", ["MultiLightGlass", "cornell_crystal", "Box_Grid"])
+def test_work_items_of_any_chunk_length_give_the_same_planes(oracle, monkeypatch, name):
+    """A launch is cut into work items (a 16x16 tile x a chunk of samples) that resident
+    workgroups take from a counter; a tile's chunks run in order, each waiting for the one
+    before it.  On a small frame with chunks of 1, 3 and 8 samples nearly every item has to
+    wait for its predecessor, which another workgroup is still tracing: planes (features
+    included), ray count and, with reference seeds, the seed state must equal those of a
+    launch with one item per tile, bit for bit -- for the fixed-size kernels with and without
+    the blur lobe and for a hierarchy scene."""
+    import ptk
+    import scenes
+    O = oracle
+    W, H = 72, 40                                        # 5 x 3 tiles, the last row and column ragged
+    sc = O.load_scene(scene_path(name))
+    results = []
+    for chunk in (None, 1, 3, 8):
+        if chunk is None:
+            monkeypatch.setenv("PTK_RENDER_CHUNK_SPP", "1000000")    # one item per tile
+        else:
+            monkeypatch.setenv("PTK_RENDER_CHUNK_SPP", str(chunk))
+        c = ptk.Context(0)
+        try:
+            got = []
+            for feats in (False, True):
+                c.set_constants(O.build_constants(sc, W, H, 4, 0.005, feats))
+                rays, glo = c.render(19, ptk.SEED_REFERENCE, PIN_SEED)
+                rays2, _ = c.render(13, ptk.SEED_COUNTER)
+                got.append((rays + rays2, glo, c.read_planes()))
+            if name == "Box_Grid":                                   # and through a hierarchy
+                c.set_scene(scenes.random_scene(300, W, H, seed=7), True)
+                rays, glo = c.render(11, ptk.SEED_REFERENCE, PIN_SEED)
+                got.append((rays, glo, c.read_planes()))
+            results.append(got)
+        finally:
+            c.close()
+    for other in results[1:]:
+        for (r0, g0, p0), (r1, g1, p1) in zip(results[0], other):
+            assert r0 == r1 and g0 == g1
+            assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+
+
 @pytest.mark.parametrize("seed", range(50, 56))
 def test_boxes_with_swapped_bounds_take_the_reference_comparison_chain(ctx, oracle, seed):
     """The slab test merges the three axes with max / min when every box of the scene has
