@@ -45,3 +45,26 @@ def test_reference_render_is_within_our_own_noise(ctx, spp):
         q = RR.quantise(shallow, RR.fit_exposure(shallow, RR.load(spp)))
         assert RR.block_diff(q, RR.load(spp)) > 3.0 * b_self
     ctx.set_stream_id(0)
+
+
+def test_reference_edgeblur_render_is_within_our_own_noise(ctx):
+    """Renders/EdgeBlur.ppm against the cornell scene: per pixel, in block means and in its
+    amount of pixel noise; four bounces instead of twelve are far outside."""
+    import ptk
+    E = RR.EDGEBLUR
+
+    def render(depth, stream):
+        raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", E["scene"] + ".scene"),
+                                        E["width"], E["height"], depth, 0.005, False)
+        ctx.set_constants(raw)
+        ctx.set_stream_id(stream)
+        ctx.render(E["spp"], ptk.SEED_COUNTER)
+        return RR.edgeblur_file_order(ctx.read_planes(0, 3), E["spp"])
+
+    first, second = render(E["depth"], 0), render(E["depth"], 1)
+    _, _, b_self = RR.check_edgeblur(first, second, "GPU, cornell %d spp, depth %d" % (E["spp"], E["depth"]))
+    shallow = render(4, 0)
+    ref = RR.load_edgeblur()
+    q = RR.quantise(shallow, RR.fit_exposure_blocks(shallow, ref))
+    assert RR.block_diff_any(q, ref) > 2.0 * b_self
+    ctx.set_stream_id(0)

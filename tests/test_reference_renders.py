@@ -47,3 +47,17 @@ def test_the_comparison_rejects_a_wrong_path_depth(oracle):
     e = RR.fit_exposure(img, ref)
     assert not (0.218 < e < 0.228)
     assert RR.block_diff(RR.quantise(img, e), ref) > 8.0
+
+
+def test_oracle_reproduces_the_reference_edgeblur_render_within_its_own_noise(oracle):
+    """Renders/EdgeBlur.ppm: the cornell scene (boxes, a rotated box, a box light), 384x216."""
+    O = oracle
+    E = RR.EDGEBLUR
+    sc = O.load_scene(os.path.join(ROOT, "data", "scenes", E["scene"] + ".scene"))
+    consts = O.build_constants(sc, E["width"], E["height"], E["depth"], 0.005, False)
+    imgs = []
+    for seed in ((0x9E3779B97F4A7C15, 0xD1B54A32D192ED03), (0x0123456789ABCDEF, 0x0F1E2D3C4B5A6978)):
+        acc = O.new_accumulators(E["width"], E["height"])
+        n, _, _ = O.render(consts, acc, E["spp"], 0, seed, threads=min(8, os.cpu_count() or 1))
+        imgs.append(RR.edgeblur_file_order(acc[0:3], n))
+    RR.check_edgeblur(imgs[0], imgs[1], "oracle, cornell %d spp, depth %d" % (E["spp"], E["depth"]))
