@@ -297,6 +297,36 @@ int ptk_denoise(ptk_ctx* ctx, const float w12[360], const float w23[100], const 
 int ptk_denoise_rows(ptk_ctx* ctx, const float w12[360], const float w23[100],
                      const float w34[70], int n, int variant, int row_begin, int row_end);
 
+/* Multi-GPU accumulation exchange for the row-band denoiser; the reference renders and
+ * denoises on one GPU (Denoiser.cpp:3-38) and has no counterpart.  GPU `rank` of `world`
+ * denoises rows [y0, y1) of the frame (contiguous bands whose sizes differ by at most one
+ * row, the first height % world ranks taking the extra one) and for that must hold the
+ * accumulators of rows [row_lo, row_hi) = the band plus `halo` rows either side (3 for the
+ * feature statistics, N for a filter of half-width N > 3), merged over all GPUs.
+ * ptk_band_layout returns that span and rows_max, the longest span of any rank (any
+ * pointer may be null). */
+int ptk_band_layout(int height, int world, int rank, int halo, int* row_lo, int* row_hi,
+                    int* rows_max);
+
+/* Lays this GPU's 16 sum planes and 16 squared-deviation planes out for one all-to-all
+ * with equal blocks: send_d[d][plane 0..31][row 0..rows_max)[x], rows [0, span length of
+ * rank d) of each plane holding rank d's span (the rest of a block is left as it is and is
+ * not read by the receiver).  send_floats >= world * 32 * rows_max * width.  The caller
+ * then exchanges block d with GPU d (ncclSend/ncclRecv pairs, all_to_all_single, ...) into
+ * a receive buffer of the same size.  Returns when the buffer is filled. */
+int ptk_pack_bands(ptk_ctx* ctx, int world, int halo, float* send_d, size_t send_floats);
+
+/* Merges what the all-to-all delivered (recv_d[s]: rank s's block for this rank) into the
+ * context's planes, rows [row_lo, row_hi) only, in one kernel, ranks added in rank order:
+ * sums add; squared deviations add with the between-rank term of the parallel-variance
+ * identity, n_s (mean_s - mean)^2, which is exact for Welford's statistic and within
+ * O(ln n / n) of the reference's order-dependent one (Renderers.cpp:860-887); stdDev =
+ * squared deviations / n.  samples_per_rank[world] are the samples each rank rendered; the
+ * context's sample count becomes their total.  Rows outside the span keep this rank's own
+ * partial sums and must not be read afterwards. */
+int ptk_merge_received(ptk_ctx* ctx, int world, int rank, int halo, const float* recv_d,
+                       size_t recv_floats, const int* samples_per_rank);
+
 /* Device addresses of the denoiser outputs (any pointer may be null). */
 int ptk_denoise_outputs_device(ptk_ctx* ctx, float** denoised_d, float** wc_sum_d,
                                float** variances_d);

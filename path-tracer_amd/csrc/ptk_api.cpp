@@ -1403,6 +1403,107 @@ int ptk_denoise_outputs_device(ptk_ctx* c, float** denoised_d, float** wc_sum_d,
     return PTK_OK;
 }
 
+namespace {
+// Rows [lo, hi) rank `rank` of `world` must hold to denoise its band: the band (contiguous,
+// sizes differ by at most one row, the first height % world ranks take the extra one) plus
+// `halo` rows either side, clipped to the image.
+void band_span(int height, int world, int rank, int halo, int& lo, int& hi)
+{
+    const int base = height / world, extra = height % world;
+    const int y0 = rank * base + std::min(rank, extra);
+    const int y1 = y0 + base + (rank < extra ? 1 : 0);
+    lo = std::max(0, y0 - halo);
+    hi = std::min(height, y1 + halo);
+}
+int check_bands(ptk_ctx* c, int world, int halo, const char* who)
+{
+    if (!c) return fail(PTK_ERR_ARG, "%s: null context", who);
+    if (!c->planes_d) return fail(PTK_ERR_STATE, "%s before ptk_set_constants", who);
+    if (world < 1 || world > PTK_MAX_RANKS)
+        return fail(PTK_ERR_ARG, "%s: %d ranks outside [1, %d]", who, world, PTK_MAX_RANKS);
+    if (halo < 0 || halo > c->height) return fail(PTK_ERR_ARG, "%s: halo %d", who, halo);
+    return PTK_OK;
+}
+}  // namespace
+
+int ptk_band_layout(int height, int world, int rank, int halo, int* row_lo, int* row_hi, int* rows_max)
+{
+    if (height < 1 || world < 1 || rank < 0 || rank >= world || halo < 0)
+        return fail(PTK_ERR_ARG, "ptk_band_layout: height %d, rank %d of %d, halo %d", height, rank,
+                    world, halo);
+    int lo = 0, hi = 0, most = 0;
+    for (int d = 0; d < world; d++) {
+        band_span(height, world, d, halo, lo, hi);
+        most = std::max(most, hi - lo);
+    }
+    band_span(height, world, rank, halo, lo, hi);
+    if (row_lo) *row_lo = lo;
+    if (row_hi) *row_hi = hi;
+    if (rows_max) *rows_max = most;
+    return PTK_OK;
+}
+
+int ptk_pack_bands(ptk_ctx* c, int world, int halo, float* send_d, size_t send_floats)
+{
+    int rc = check_bands(c, world, halo, "ptk_pack_bands");
+    if (rc != PTK_OK) return rc;
+    if (!send_d) return fail(PTK_ERR_ARG, "ptk_pack_bands: null buffer");
+    int rows_max = 0;
+    ptk_band_layout(c->height, world, 0, halo, nullptr, nullptr, &rows_max);
+    const size_t W = (size_t)c->width, block = 32 * (size_t)rows_max * W;
+    if (send_floats < (size_t)world * block)
+        return fail(PTK_ERR_ARG, "ptk_pack_bands: buffer of %zu floats, %zu needed", send_floats,
+                    (size_t)world * block);
+    if ((rc = bind(c)) != PTK_OK) return rc;
+    for (int d = 0; d < world; d++) {
+        int lo, hi;
+        band_span(c->height, world, d, halo, lo, hi);
+        // 32 planes, each a run of (hi - lo) rows: one strided copy per destination
+        HIP_TRY(hipMemcpy2DAsync(send_d + (size_t)d * block, (size_t)rows_max * W * sizeof(float),
+                                 c->planes_d + (size_t)lo * W, c->pixels * sizeof(float),
+                                 (size_t)(hi - lo) * W * sizeof(float), 32, hipMemcpyDeviceToDevice,
+                                 c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's exchange runs on a stream of its own
+    return PTK_OK;
+}
+
+int ptk_merge_received(ptk_ctx* c, int world, int rank, int halo, const float* recv_d,
+                       size_t recv_floats, const int* samples_per_rank)
+{
+    int rc = check_bands(c, world, halo, "ptk_merge_received");
+    if (rc != PTK_OK) return rc;
+    if (!recv_d || !samples_per_rank) return fail(PTK_ERR_ARG, "ptk_merge_received: null argument");
+    if (rank < 0 || rank >= world) return fail(PTK_ERR_ARG, "ptk_merge_received: rank %d of %d", rank, world);
+    BandMergeArgs a;
+    a.recv = recv_d;
+    a.planes = c->planes_d;
+    a.width = c->width;
+    a.height = c->height;
+    a.world = world;
+    ptk_band_layout(c->height, world, rank, halo, &a.row_lo, &a.row_hi, &a.rows_max);
+    if (recv_floats < (size_t)world * 32 * (size_t)a.rows_max * (size_t)c->width)
+        return fail(PTK_ERR_ARG, "ptk_merge_received: buffer of %zu floats, %zu needed", recv_floats,
+                    (size_t)world * 32 * (size_t)a.rows_max * (size_t)c->width);
+    int64_t total = 0;
+    for (int r = 0; r < world; r++) {
+        if (samples_per_rank[r] < 0)
+            return fail(PTK_ERR_ARG, "ptk_merge_received: rank %d rendered %d samples", r, samples_per_rank[r]);
+        a.n_rank[r] = (float)samples_per_rank[r];
+        total += samples_per_rank[r];
+    }
+    if (total < 1 || total > 0x7fffffff)
+        return fail(PTK_ERR_ARG, "ptk_merge_received: %lld samples in all", (long long)total);
+    a.n_total = (float)total;
+    if ((rc = bind(c)) != PTK_OK) return rc;
+    HIP_TRY(ptk_launch_merge_received(a, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sample_count = (int)total;
+    c->have_features = true;
+    c->have_denoised = false;
+    return PTK_OK;
+}
+
 int ptk_save_target(ptk_ctx* c)
 {
     if (!c) return fail(PTK_ERR_ARG, "ptk_save_target: null context");

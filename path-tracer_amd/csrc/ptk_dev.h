@@ -252,3 +252,16 @@ hipError_t ptk_launch_save_target(const float* planes, float* target, size_t pix
 // lds_tiles: N = 1 also takes the LDS-tile kernel that serves the wider windows (same
 // arithmetic, kept callable so the two forms can be compared bit for bit).
 hipError_t ptk_launch_filter(const DenoiseArgs& a, hipStream_t stream, bool lds_tiles = false);
+
+// Merge of the accumulators received from every rank for this rank's row span (bands.hip).
+// recv: [world][32 planes: 16 sums, 16 squared deviations][rows_max][width]; rows
+// [0, row_hi - row_lo) of each plane block are this rank's span as source r rendered it.
+#define PTK_MAX_RANKS 64
+struct BandMergeArgs {
+    const float* recv;
+    float* planes;          // PTK_N_PLANES * P floats, rows [row_lo, row_hi) are written
+    int32_t width, height, row_lo, row_hi, rows_max, world;
+    float n_total;
+    float n_rank[PTK_MAX_RANKS];
+};
+hipError_t ptk_launch_merge_received(const BandMergeArgs& a, hipStream_t stream);

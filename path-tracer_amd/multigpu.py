@@ -139,7 +139,13 @@ def merge_to_bands(planes, n_local, width, height, halo=3, group=None, ctx=None)
     between-rank term n_r (mean_r - mean)^2, stdDev = sdv / n.  Ranks are added in
     rank order, so a row two ranks both hold (a halo row) gets the same bits on both.
     planes: (38, P) tensor; rows outside [lo, hi) are left as they were and must not be
-    read afterwards.  Returns (n_total, lo, hi)."""
+    read afterwards.  Returns (n_total, lo, hi).
+
+    When `planes` is the zero-copy view of a context's HBM planes (pass the context), the
+    work on either side of the all-to-all is the library's own: ptk_pack_bands lays the send
+    buffer out with one strided device copy per destination and ptk_merge_received merges
+    the receive buffer in one kernel that reads it once (IEEE fp32, ranks in order).  The
+    tensor code below states the same rule for host tensors (the CPU tests)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     W, H = int(width), int(height)
@@ -157,6 +163,17 @@ def merge_to_bands(planes, n_local, width, height, halo=3, group=None, ctx=None)
     all_reduce_(counts, group)
     n_r = [int(round(float(x))) for x in counts.tolist()]
     n_total = sum(n_r)
+
+    if ctx is not None and planes.is_cuda:
+        send = torch.empty((world, 32, rows_max, W), dtype=planes.dtype, device=dev)
+        torch.cuda.current_stream(dev).synchronize()      # the context has its own stream
+        ctx.pack_bands(world, halo, send.data_ptr(), send.numel())
+        recv = torch.empty_like(send)
+        _all_to_all_single(recv, send, group)
+        del send
+        torch.cuda.current_stream(dev).synchronize()
+        ctx.merge_received(world, rank, halo, recv.data_ptr(), recv.numel(), n_r)
+        return n_total, lo, hi
 
     img = planes.view(N_PLANES_TOTAL, H, W)
     send = torch.zeros((world, 32, rows_max, W), dtype=planes.dtype, device=dev)
@@ -243,16 +260,33 @@ def denoise_sharded(ctx, weights, n, device, variant=0, group=None, n_total=None
     den, wc = device_denoised(ctx, device)
     ctx.denoise_rows(weights, n, variant, y0, y1)       # returns when the band is written
     if world > 1:
-        rows_max = max(b - a for a, b in (row_band(H, world, r) for r in range(world)))
-        part = torch.zeros((4, rows_max, W), dtype=den.dtype, device=den.device)
-        part[0:3, :y1 - y0] = den.view(3, H, W)[:, y0:y1]
-        part[3, :y1 - y0] = wc.view(H, W)[y0:y1]
-        full = torch.empty((world, 4, rows_max, W), dtype=den.dtype, device=den.device)
-        _all_gather_into(full, part, group)
-        for r in range(world):
-            a, b = row_band(H, world, r)
-            if r != rank:
-                den.view(3, H, W)[:, a:b] = full[r, 0:3, :b - a]
-                wc.view(H, W)[a:b] = full[r, 3, :b - a]
+        gather_bands_(den.view(3, H, W), wc.view(H, W), world, rank, group)
         torch.cuda.current_stream(den.device).synchronize() if den.is_cuda else None
     return den
+
+
+def gather_bands_(den, wc, world, rank, group=None):
+    """Every rank's band of the three colour planes den (3, H, W) and of the weight-sum plane
+    wc (H, W) to every rank, in place.  A band's rows of one plane are contiguous and the
+    bands tile the plane in rank order, so when the height divides evenly each plane IS the
+    concatenation an all-gather produces and the collective writes the peers' bands
+    straight to where they belong (four all-gathers, no staging).  Ragged bands go through
+    one padded all-gather."""
+    H, W = wc.shape
+    if H % world == 0 and not (den.is_cuda and dist.get_backend(group) == "gloo"):
+        rows = H // world
+        for plane in (den[0], den[1], den[2], wc):
+            dist.all_gather_into_tensor(plane, plane[rank * rows:(rank + 1) * rows], group=group)
+        return
+    y0, y1 = row_band(H, world, rank)
+    rows_max = max(b - a for a, b in (row_band(H, world, r) for r in range(world)))
+    part = torch.empty((4, rows_max, W), dtype=den.dtype, device=den.device)
+    part[0:3, :y1 - y0] = den[:, y0:y1]
+    part[3, :y1 - y0] = wc[y0:y1]
+    full = torch.empty((world, 4, rows_max, W), dtype=den.dtype, device=den.device)
+    _all_gather_into(full, part, group)
+    for r in range(world):
+        a, b = row_band(H, world, r)
+        if r != rank:
+            den[:, a:b] = full[r, 0:3, :b - a]
+            wc[a:b] = full[r, 3, :b - a]

@@ -26,7 +26,8 @@ EXPORTS = [
     "ptk_set_sample_count", "ptk_refresh_std_dev", "ptk_auto_exposure", "ptk_denoise",
     "ptk_denoise_rows", "ptk_denoise_outputs_device", "ptk_post_process", "ptk_save_target",
     "ptk_set_target", "ptk_train_step", "ptk_timing", "ptk_synchronize", "ptk_set_scene",
-    "ptk_check_scene", "ptk_set_camera", "ptk_auto_exposure_static",
+    "ptk_check_scene", "ptk_set_camera", "ptk_auto_exposure_static", "ptk_band_layout",
+    "ptk_pack_bands", "ptk_merge_received",
 ]
 SCENE_VISIT_ALL = 1
 SCENE_ATTRS = 13
@@ -162,6 +163,10 @@ def load():
     L.ptk_check_scene.argtypes = [C.POINTER(SceneDesc), C.POINTER(SceneStats)]
     L.ptk_auto_exposure_static.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vp,
                                            vp, vp]
+    ip = C.POINTER(C.c_int)
+    L.ptk_band_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip]
+    L.ptk_pack_bands.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+    L.ptk_merge_received.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, ip]
     L.ptk_timing.argtypes = [vp, C.POINTER(Times)]
     L.ptk_synchronize.argtypes = [vp]
     for name in EXPORTS:
@@ -169,6 +174,15 @@ def load():
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def band_layout(height, world, rank, halo):
+    """(row_lo, row_hi, rows_max) of ptk_band_layout."""
+    lo, hi, most = C.c_int(), C.c_int(), C.c_int()
+    rc = load().ptk_band_layout(height, world, rank, halo, C.byref(lo), C.byref(hi), C.byref(most))
+    if rc != 0:
+        raise PtkError(load().ptk_last_error().decode())
+    return lo.value, hi.value, most.value
 
 
 def _fp(a):
@@ -339,6 +353,19 @@ class Context:
         self._check(self._L.ptk_denoise_outputs_device(self._h, C.byref(d), C.byref(w),
                                                        C.byref(v)))
         return int(d.value), int(w.value), int(v.value)
+
+    def pack_bands(self, world, halo, send_ptr, send_floats):
+        """Fills the device buffer at `send_ptr` with this GPU's planes laid out per destination
+        rank (ptk_pack_bands)."""
+        self._check(self._L.ptk_pack_bands(self._h, world, halo, C.c_void_p(send_ptr),
+                                           C.c_size_t(send_floats)))
+
+    def merge_received(self, world, rank, halo, recv_ptr, recv_floats, samples_per_rank):
+        """Merges the blocks received from every rank into the planes of this rank's row span
+        (ptk_merge_received); the context's sample count becomes the total."""
+        n = (C.c_int * world)(*[int(x) for x in samples_per_rank])
+        self._check(self._L.ptk_merge_received(self._h, world, rank, halo, C.c_void_p(recv_ptr),
+                                               C.c_size_t(recv_floats), n))
 
     def post_process(self, metric=0, exposure=1.0, g=2.2, want_post=True, want_rgb8=False):
         """Returns (postScreen (P, 3) float32 | None, rgb8 (H, W, 3) uint8 top row first | None)."""

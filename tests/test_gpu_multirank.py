@@ -52,7 +52,7 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), planes=merged, denoised=den_a,
              n_total=n_total, banded=planes.cpu().numpy(), denoised_b=den.cpu().numpy(),
-             span=np.array([lo, hi]))
+             span=np.array([lo, hi]), own=own.cpu().numpy(), n_local=n_local)
     ctx.close()
     dist.destroy_process_group()
 
@@ -70,14 +70,42 @@ def test_two_ranks_on_one_gpu_match_a_single_context(tmp_path):
     assert np.array_equal(r0["planes"], r1["planes"], equal_nan=True)
     # after the gather both ranks hold the same full image
     assert np.array_equal(r0["denoised"], r1["denoised"], equal_nan=True)
-    # the band-wise exchange gives each rank the same merged values on its span, and the
-    # same denoised frame
+    # The band-wise exchange (ptk_pack_bands, all-to-all, ptk_merge_received) gives each rank,
+    # on its span, exactly what its stated rule gives in IEEE fp32 with the ranks in order ...
+    own = [r0["own"].reshape(38, H, W), r1["own"].reshape(38, H, W)]
+    n_r = [np.float32(int(r0["n_local"])), np.float32(int(r1["n_local"]))]
+    n_all = np.float32(TOTAL_SPP)
     for r in (r0, r1):
         lo, hi = (int(x) for x in r["span"])
+        x = [o[0:16, lo:hi] for o in own]
+        v = [o[16:32, lo:hi] for o in own]
+        sums = x[0] + x[1]
+        mean = sums / n_all
+        sdv = None
+        for k in range(2):
+            d = x[k] / n_r[k] - mean
+            part = v[k] + n_r[k] * (d * d)
+            sdv = part if sdv is None else sdv + part
+        sd = np.stack([(sdv[3 * j] + sdv[3 * j + 1] + sdv[3 * j + 2]) / n_all for j in range(5)]
+                      + [sdv[15] / n_all])
         a = r["banded"].reshape(38, H, W)[:, lo:hi]
+        assert sums.dtype == np.float32 and sd.dtype == np.float32
+        assert np.array_equal(a[0:16], sums, equal_nan=True)
+        assert np.array_equal(a[16:32], sdv, equal_nan=True)
+        assert np.array_equal(a[32:38], sd, equal_nan=True)
+        # ... and leaves the rows outside the span as the rank rendered them
+        k = 0 if r is r0 else 1
+        rest = np.ones(H, bool)
+        rest[lo:hi] = False
+        assert np.array_equal(r["banded"].reshape(38, H, W)[:32, rest], own[k][:32, rest], equal_nan=True)
+        # the whole-frame merge (all-reduce, tensor arithmetic with a reciprocal for the
+        # scalar division) agrees: sums bit for bit, deviations to rounding
         b = r["planes"].reshape(38, H, W)[:, lo:hi]
-        assert np.array_equal(a, b, equal_nan=True)
-        assert np.array_equal(r["denoised_b"], r0["denoised"], equal_nan=True)
+        assert np.array_equal(a[0:16], b[0:16], equal_nan=True)
+        scale = np.abs(b[16:]).max(axis=(1, 2), keepdims=True).clip(1e-6)
+        assert (np.abs(a[16:] - b[16:]) / scale).max() < 1e-5
+    # both ranks end with the same denoised frame (halo rows carry the same bits on both)
+    assert np.array_equal(r0["denoised_b"], r1["denoised_b"], equal_nan=True)
 
     # the same job in one process: render each stream, merge by the same rule on the host
     raw, _, _ = ptk.scene_constants(scene_path("MultiLightGlass"), W, H, 4, 0.005, True)
@@ -106,7 +134,16 @@ def test_two_ranks_on_one_gpu_match_a_single_context(tmp_path):
 
     ctx.write_planes(r0["planes"], TOTAL_SPP)
     full = ctx.denoise(w, NWIN, 0)
-    ctx.close()
     ref = full["denoised"].T
     # the same two-pass kernels on the same planes: bit-identical in both bands
     assert np.array_equal(r0["denoised"], ref, equal_nan=True)
+    # and the band-merged frame: each rank's band denoised from its span of merged planes
+    # equals the whole frame denoised from those planes stitched together
+    stitched = r0["banded"].reshape(38, H, W).copy()
+    lo1, hi1 = (int(x) for x in r1["span"])
+    y0 = multigpu.row_band(H, world, 1)[0]
+    stitched[:, y0:] = r1["banded"].reshape(38, H, W)[:, y0:]
+    ctx.write_planes(stitched.reshape(38, H * W), TOTAL_SPP)
+    full_b = ctx.denoise(w, NWIN, 0)
+    ctx.close()
+    assert np.array_equal(r0["denoised_b"], full_b["denoised"].T, equal_nan=True)
