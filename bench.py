@@ -35,7 +35,8 @@ import ptk  # noqa: E402
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector fp32 peak (FMA = 2 flop)
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
 PEAK_VALU_ISSUE_T = 78.6   # lane-instructions/s: 256 CUs x 4 SIMDs x 32 lanes/cycle x 2.4 GHz
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02_profile_summary.json")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r03_profile_summary.json")
+PROFILE_STALE_TOLERANCE = 0.02   # a committed profile speaks for this run only if its launch time agrees
 
 
 def load_opcount(scene):
@@ -124,15 +125,18 @@ def denoise_probe(ctx, W, H, depth):
     render_ms = ctx.timing().render_ms
     out = {"workload": "MultiLightGlass %dx%d 128 spp + denoise N=1 BEST.txt" % (W, H),
            "render_msamples_per_s": W * H * 128 / render_ms / 1e3}
-    ts = []
-    for _ in range(12):
-        t0 = time.perf_counter()
-        ctx.denoise(w, 1, 0, want_outputs=False)
-        wall = (time.perf_counter() - t0) * 1e3
-        t = ctx.timing()
-        ts.append((t.denoise_ms, t.features_ms, t.filter_ms, wall))
-    ts = ts[2:]
-    avg = [sum(x[i] for x in ts) / len(ts) for i in range(4)]
+    def timed_denoise(variant):
+        ts = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            ctx.denoise(w, 1, variant, want_outputs=False)
+            wall = (time.perf_counter() - t0) * 1e3
+            t = ctx.timing()
+            ts.append((t.denoise_ms, t.features_ms, t.filter_ms, wall))
+        ts = ts[2:]
+        return [sum(x[i] for x in ts) / len(ts) for i in range(4)]
+
+    avg = timed_denoise(0)
     out["two_pass_ms"] = avg[0]
     # host clock around the whole ptk_denoise call (argument checks, both launches, one wait)
     out["call_wall_ms"] = avg[3]
@@ -140,6 +144,13 @@ def denoise_probe(ctx, W, H, depth):
     # algorithmic bytes per pixel: features 72 read + 28 written, filter 116 read + 16 written
     out["features_gbs"] = W * H * 100 / avg[1] / 1e6
     out["filter_gbs"] = W * H * 132 / avg[2] / 1e6
+    # variant 2: the feature pass in its tolerance-held form (smooth statistics formed a
+    # cheaper way, discrete ones bit for bit; tests/test_gpu_denoise_fast.py holds it to 2e-5)
+    fast = timed_denoise(2)
+    out["tolerance_held_features"] = {
+        "variant": 2, "two_pass_ms": fast[0], "features_ms": fast[1], "filter_ms": fast[2],
+        "features_gbs": W * H * 100 / fast[1] / 1e6,
+        "features_frac": W * H * 100 / fast[1] / 1e6 / PEAK_HBM_GBS}
     es = []
     for _ in range(12):
         ctx.auto_exposure(ptk.EXPOSURE_CPU)
@@ -186,15 +197,55 @@ def denoise_probe(ctx, W, H, depth):
         try:
             with open(PROFILE_SUMMARY) as f:
                 ks = json.load(f)["kernels"]
-            per_px = {"features_mlp_kernel<false>": 100, "filter_rows_kernel": 132,
-                      "exposure_kernel<0>": 12, "post_process_kernel<4>": 24}
+            per_px = {"features_mlp_kernel<false>": 100, "features_mlp_fast_kernel<false>": 100,
+                      "filter_rows_kernel": 132, "exposure_kernel<0>": 12, "post_process_kernel<4>": 24}
             out["rocprof_kernel_trace"] = {
                 name: {"avg_us": ks[name]["avg_ms"] * 1e3, "min_us": ks[name]["min_ms"] * 1e3,
                        "gbs_at_avg": W * H * b / ks[name]["avg_ms"] / 1e6}
                 for name, b in per_px.items() if name in ks}
-            out["rocprof_kernel_trace"]["source"] = "profiles/r02_profile_summary.json (committed run)"
+            out["rocprof_kernel_trace"]["source"] = "profiles/%s (committed run)" % os.path.basename(PROFILE_SUMMARY)
         except (OSError, KeyError, ValueError):
             pass
+    return out
+
+
+def denoise_4k_probe(ctx, depth):
+    """The denoiser at 3840x2160 on a rendered frame (MultiLightGlass, 32 spp with features,
+    BEST.txt, N = 1).  The 1080p frame's 240 MB of filter input fit the 256 MB Infinity
+    Cache, and the feature pass that runs just before the filter has read most of them; at
+    this size (1.26 GB of planes) the stencils stream from HBM, so these are the figures to
+    hold against the HBM peak."""
+    W, H = 3840, 2160
+    raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", "MultiLightGlass.scene"),
+                                    W, H, depth, 0.005, True)
+    w = ptk.load_weights(os.path.join(ROOT, "data", "weights", "BEST.txt"))
+    ctx.set_constants(raw)
+    ctx.render(32, ptk.SEED_COUNTER)
+    out = {"workload": "MultiLightGlass %dx%d 32 spp + denoise N=1 BEST.txt" % (W, H),
+           "render_msamples_per_s": W * H * 32 / ctx.timing().render_ms / 1e3}
+    for variant, tag in ((0, ""), (2, "_tolerance_held")):
+        ts = []
+        for _ in range(10):
+            ctx.denoise(w, 1, variant, want_outputs=False)
+            t = ctx.timing()
+            ts.append((t.features_ms, t.filter_ms))
+        ts = ts[2:]
+        f_ms, g_ms = (sum(x[i] for x in ts) / len(ts) for i in range(2))
+        out["features%s_ms" % tag] = f_ms
+        out["features%s_gbs" % tag] = W * H * 100 / f_ms / 1e6
+        out["features%s_frac" % tag] = W * H * 100 / f_ms / 1e6 / PEAK_HBM_GBS
+        if variant == 0:
+            out["filter_ms"] = g_ms
+            out["filter_gbs"] = W * H * 132 / g_ms / 1e6
+            out["filter_frac"] = out["filter_gbs"] / PEAK_HBM_GBS
+    es = []
+    for _ in range(10):
+        ctx.auto_exposure(ptk.EXPOSURE_CPU)
+        es.append(ctx.timing().exposure_ms)
+    e = sum(es[2:]) / len(es[2:])
+    out["exposure_ms"] = e
+    out["exposure_gbs"] = W * H * 12 / e / 1e6
+    out["exposure_frac"] = out["exposure_gbs"] / PEAK_HBM_GBS
     return out
 
 
@@ -224,6 +275,38 @@ def _max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     multigpu.all_reduce_(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def config2_split_leg(ctx, args, rank, world, gpu, device):
+    """BASELINE.json configs[1] as one job on all ranks (strong scaling): cornell_crystal
+    1920x1080, the frame's 2000 samples per pixel split across the ranks, one all-reduce of
+    the colour planes."""
+    W, H = 1920, 1080
+    total = 2000
+    raw, _, _ = ptk.scene_constants(os.path.join(ROOT, "data", "scenes", "cornell_crystal.scene"),
+                                    W, H, args.depth, 0.005, False)
+    ctx.set_constants(raw)
+    ctx.set_stream_id(rank)
+    planes = multigpu.device_planes(ctx, device)
+    n_local = multigpu.shard_spp(total, world, rank)
+    ctx.render(8, ptk.SEED_COUNTER)
+    multigpu.all_reduce_(planes[0:3])
+    ctx.reset()
+    ctx.synchronize()
+    _barrier(args, gpu)
+    t0 = time.perf_counter()
+    ctx.render(n_local, ptk.SEED_COUNTER)
+    t1 = time.perf_counter()
+    multigpu.all_reduce_(planes[0:3])
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    _barrier(args, gpu)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, device)
+    return {"workload": "Scenes/cornell_crystal.scene %dx%d, %d spp split over %d GPUs (strong scaling), "
+                        "all-reduce of the colour planes" % (W, H, total, world),
+            "msamples_per_s": float(W) * H * total / elapsed / 1e6, "frame_ms": elapsed * 1e3,
+            "render_ms_rank0": (t1 - t0) * 1e3, "exchange_ms_rank0": (t2 - t1) * 1e3,
+            "exchange_bytes_per_rank": multigpu.exchange_bytes(W, H, world, features=False)}
 
 
 def config4_leg(ctx, args, rank, world, gpu, device):
@@ -320,8 +403,12 @@ def main():
                     help="run the multi-rank exchange path even with one rank (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-denoise-probe", action="store_true")
+    ap.add_argument("--no-denoise-4k", action="store_true",
+                    help="skip the 3840x2160 denoiser probe (profiling runs: keeps one frame size per kernel)")
     ap.add_argument("--no-multi-gpu-legs", action="store_true",
                     help="skip the 3840x2160 config 4 / config 5 legs of a multi-rank run")
+    ap.add_argument("--leg-timeout", type=int, default=900,
+                    help="seconds the multi-rank legs may take before the headline is printed without them")
     ap.add_argument("--leg-width", type=int, default=3840)
     ap.add_argument("--leg-height", type=int, default=2160)
     args = ap.parse_args()
@@ -418,11 +505,36 @@ def main():
     }
     legs = {}
     if use_dist and not args.no_multi_gpu_legs:
-        for name, fn in (("config4", config4_leg), ("config5", config5_leg)):
+        # A rank that fails inside a leg leaves the others waiting in the leg's collectives.
+        # Two guards keep the result line: a watchdog that prints the headline as it stands
+        # and ends the process when the legs overrun, and after each leg an agreement (MIN
+        # over ranks of an ok flag) on whether to go on.
+        import threading
+
+        def overrun():
+            if rank == 0:
+                out.update(legs)
+                out["legs_error"] = "the multi-rank legs did not finish within %d s" % args.leg_timeout
+                print(json.dumps(out), file=result_out, flush=True)
+            os._exit(0 if rank == 0 else 3)
+
+        watchdog = threading.Timer(args.leg_timeout, overrun)
+        watchdog.daemon = True
+        watchdog.start()
+        for name, fn in (("config2_split", config2_split_leg), ("config4", config4_leg),
+                         ("config5", config5_leg)):
             try:
                 legs[name] = fn(ctx, args, rank, world, gpu, device)
+                ok = 1.0
             except Exception as exc:   # a leg must not cost the run its result line
                 legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                ok = 0.0
+            flag = torch.tensor([ok], dtype=torch.float64, device=device)
+            multigpu.all_reduce_(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 0.5:
+                legs.setdefault("legs_error", "a rank failed in %s; the remaining legs were skipped" % name)
+                break
+        watchdog.cancel()
     if rank == 0:
         out.update(legs)
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
@@ -445,6 +557,13 @@ def main():
             }
             prof = load_profile(int(samples_per_launch), False) if args.scene == "cornell_crystal" \
                 else None
+            if prof and "pmc_per_launch" in prof and \
+                    abs(prof.get("avg_ms", 0.0) / avg_ms - 1.0) > PROFILE_STALE_TOLERANCE:
+                out["roofline"]["profile_note"] = (
+                    "%s was taken on a launch of %.3f ms, this run's is %.3f ms: its counters are "
+                    "not quoted (rerun scripts/collect_profiles.sh)" % (
+                        os.path.basename(PROFILE_SUMMARY), prof.get("avg_ms", 0.0), avg_ms))
+                prof = None
             if prof and "pmc_per_launch" in prof:
                 pmc = prof["pmc_per_launch"]
                 if "hbm_read_bytes_per_launch" in prof:
@@ -452,8 +571,8 @@ def main():
                                                   + prof["hbm_write_bytes_per_launch"])
                     out["roofline"]["traffic_note"] = (
                         "rocprofv3 FETCH_SIZE (x calibration) + WRITE_SIZE per launch from "
-                        "profiles/r02_profile_summary.json: register-spill scratch traffic, "
-                        "not plane traffic")
+                        "profiles/%s: register-spill scratch traffic, not plane traffic"
+                        % os.path.basename(PROFILE_SUMMARY))
                 if "SQ_INSTS_VALU" in pmc:
                     lane_instr = pmc["SQ_INSTS_VALU"] * 64.0
                     rate = lane_instr / (avg_ms * 1e-3) / 1e12
@@ -471,6 +590,8 @@ def main():
         if world == 1 and not args.force_dist:
             if not args.no_denoise_probe:
                 out["denoise"] = denoise_probe(ctx, W, H, args.depth)
+                if not args.no_denoise_4k:
+                    out["denoise_4k"] = denoise_4k_probe(ctx, args.depth)
                 out["scene_hierarchy"] = hierarchy_probe(ctx, W, H)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth)

@@ -8,10 +8,10 @@ export TMPDIR=/tmp
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-SHORT="--steps 2 --warmup 1 --spp-per-step 200 --no-cpu-baseline"
+SHORT="--steps 2 --warmup 1 --spp-per-step 200 --no-cpu-baseline --no-denoise-4k"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- \
-    python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json"
+    python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-denoise-4k > "$OUT/bench_under_rocprof.json"
 echo "kernel trace done"
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES \
     --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $SHORT > "$OUT/pmc_sq.json"
