@@ -233,6 +233,9 @@ int ptk_write_planes(ptk_ctx* ctx, int first_plane, int n_planes, const float* i
  * of PTK_N_PLANES * P floats). */
 int ptk_planes_device(ptk_ctx* ctx, float** base_d, size_t* pixels_per_plane);
 int ptk_get_sample_count(ptk_ctx* ctx, int* sample_count);
+/* Declares the planes valid for `sample_count` samples (after the caller has written them
+ * through the device address): on a context configured with want_denoise_features this
+ * covers the feature planes, which ptk_denoise then accepts. */
 int ptk_set_sample_count(ptk_ctx* ctx, int sample_count);
 
 /* Recomputes planes PTK_PL_SD from sum and sum-of-squares style planes after a
@@ -258,7 +261,11 @@ int ptk_auto_exposure(ptk_ctx* ctx, int formula, float* exposure, double* raw_su
  * performs no hipMalloc / hipFree and no host<->device copy.  pixels above
  * PTK_STATIC_MAX_PIXELS is PTK_ERR_ARG.  All calls on one GPU share that array:
  * calls that overlap on one GPU (other streams or threads) race; issue them on
- * one stream. */
+ * one stream.  colour_planes_d needs 4-byte alignment only (16-byte aligned planes take
+ * the 16-byte loads, others the one-pixel loop).  The FIRST call on each GPU looks the
+ * array's address up (a mutex, and possibly the loading of the library's code object onto
+ * that GPU, which allocates): make it outside graph capture, or after a ptk_create on that
+ * GPU, which performs the same look-up. */
 #define PTK_STATIC_MAX_PIXELS ((size_t)1 << 28)
 int ptk_auto_exposure_static(const float* colour_planes_d, size_t pixels, int width, int height,
                              int sample_count, int formula, float* exposure_d, double* raw_sum_d,

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void exposure_kernel(const float* __restrict__
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     double part = 0.0;
-    if ((P & 3) == 0) {
+    // 16-byte loads need all three planes 16-byte aligned: a pixel count that is a multiple of
+    // four and an aligned base; anything else (a caller's sub-view at a 4-byte offset) takes
+    // the one-pixel loop
+    if ((P & 3) == 0 && ((unsigned long long)planes & 15ull) == 0) {
         const size_t n4 = P >> 2;
         const float4* r4 = (const float4*)pr;
         const float4* g4 = (const float4*)pg;

@@ -1115,7 +1115,7 @@ int ptk_render(ptk_ctx* c, int spp, int seed_mode, uint64_t glo_seed[2], uint64_
     HIP_TRY(hipMemcpyAsync(&rays, c->rays_d, sizeof rays, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (rays_out) *rays_out = rays;
-    if (c->features && spp > 0) c->have_features = true;
+    if (spp > 0) c->have_features = c->features;   // a colour-only render leaves the feature planes behind
     c->times.render_ms = render_ms;
     c->times.seed_ms = seed_ms;
     c->times.render_samples = (uint64_t)P * (uint64_t)spp;
@@ -1206,6 +1206,10 @@ int ptk_set_sample_count(ptk_ctx* c, int sample_count)
 {
     if (!c || sample_count < 0) return fail(PTK_ERR_ARG, "ptk_set_sample_count: bad argument");
     c->sample_count = sample_count;
+    // A caller that fills the planes through ptk_planes_device (a cross-GPU reduction) declares
+    // them valid with this call: on a context set up for the denoiser's features that covers
+    // the feature planes too.
+    if (c->features && sample_count > 0) c->have_features = true;
     return PTK_OK;
 }
 

@@ -42,3 +42,37 @@ def test_checker_flags_a_planted_hazard(tmp_path):
                         str(bad)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1
     assert "2 hazards" in r.stdout, r.stdout
+
+
+def _run_checker(path):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_dpp_hazard.py"),
+                           str(path)], capture_output=True, text=True, timeout=60)
+
+
+def test_checker_follows_branches_to_a_label(tmp_path):
+    """A vector write just before a loop's back edge and a DPP read at the top of the loop are
+    one wait state apart (the branch); the same with two s_nop after the label is fine."""
+    dpp = "\tv_sub_f32_dpp v4, v1, v5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+    loop = ("\tv_mov_b32_e32 v9, 0\n\ts_nop 3\n.LBB0_1:\n%s" + dpp +
+            "\ts_add_i32 s0, s0, 1\n\ts_cmp_lt_i32 s0, 8\n\tv_add_f32_e32 v1, v2, v3\n"
+            "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    bad = tmp_path / "loop_bad.s"
+    bad.write_text(loop % "")
+    r = _run_checker(bad)
+    assert r.returncode == 1 and "1 hazards" in r.stdout, r.stdout
+    good = tmp_path / "loop_good.s"
+    good.write_text(loop % "\ts_nop 0\n")
+    r = _run_checker(good)
+    assert r.returncode == 0, r.stdout
+
+
+def test_checker_flags_a_vector_write_of_exec(tmp_path):
+    dpp = "\tv_sub_f32_dpp v4, v1, v5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+    bad = tmp_path / "exec_bad.s"
+    bad.write_text("\tv_cmpx_gt_f32_e32 v2, v3\n\ts_nop 2\n" + dpp)
+    r = _run_checker(bad)
+    assert r.returncode == 1 and "EXEC" in r.stdout, r.stdout
+    good = tmp_path / "exec_good.s"
+    good.write_text("\tv_cmpx_gt_f32_e32 v2, v3\n\ts_nop 4\n" + dpp)
+    r = _run_checker(good)
+    assert r.returncode == 0, r.stdout

@@ -67,6 +67,25 @@ def test_static_exposure_matches_the_allocating_entry_point(oracle):
             torch.cuda.synchronize()
             _, raw0 = oracle.auto_exposure(full, W, H, spp, 0)
             assert abs(float(out_raw.item()) - raw0) <= 1e-9 * abs(raw0)
+        # planes at a 4-byte offset from a 16-byte boundary (a caller's sub-view), pixel count a
+        # multiple of four: the 16-byte loads do not apply, the result is the same
+        Wv, Hv, sppv = 64, 36, 3
+        Pv = Wv * Hv
+        host = (np.random.default_rng(5).random(3 * Pv, dtype=np.float32) * np.float32(sppv))
+        backing = torch.zeros(3 * Pv + 1, dtype=torch.float32, device=dev)
+        backing[1:] = torch.from_numpy(host).to(dev)
+        view_ptr = backing.data_ptr() + 4
+        assert view_ptr % 16 == 4
+        torch.cuda.synchronize()
+        rc = L.ptk_auto_exposure_static(C.c_void_p(view_ptr), Pv, Wv, Hv, sppv, 0,
+                                        C.c_void_p(out_e.data_ptr()), C.c_void_p(out_raw.data_ptr()), None)
+        assert rc == 0, L.ptk_last_error().decode()
+        torch.cuda.synchronize()
+        full = np.zeros((38, Pv), np.float32)
+        full[0:3] = host.reshape(3, Pv)
+        e_cpu, raw_cpu = oracle.auto_exposure(full, Wv, Hv, sppv, 0)
+        assert abs(float(out_raw.item()) - raw_cpu) <= 1e-9 * abs(raw_cpu)
+        assert abs(float(out_e.item()) - e_cpu) <= 3e-4 * abs(e_cpu)
         # argument checks: nothing is launched
         base, P = ctx.planes_device()
         bad = [
