@@ -823,6 +823,29 @@ def test_work_items_of_any_chunk_length_give_the_same_planes(oracle, monkeypatch
             assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
 
 
+def test_work_item_hand_over_at_full_occupancy(oracle, monkeypatch):
+    """The same at a size that fills the chip (1280x720: 3600 tiles on about 1500 resident
+    workgroups, spread over all eight L2s), chunks of 8 samples: a tile's chunks are traced
+    by whichever workgroup is free, so every hand-over of the sums crosses compute units and
+    mostly L2s.  Colour and all feature planes bit-identical to one item per tile."""
+    import ptk
+    O = oracle
+    W, H = 1280, 720
+    sc = O.load_scene(scene_path("MultiLightGlass"))
+    got = []
+    for chunk in ("1000000", "8"):
+        monkeypatch.setenv("PTK_RENDER_CHUNK_SPP", chunk)
+        c = ptk.Context(0)
+        try:
+            c.set_constants(O.build_constants(sc, W, H, 4, 0.005, True))
+            rays, _ = c.render(48, ptk.SEED_COUNTER)
+            got.append((rays, c.read_planes()))
+        finally:
+            c.close()
+    assert got[0][0] == got[1][0]
+    assert np.array_equal(got[0][1].view(np.uint32), got[1][1].view(np.uint32))
+
+
 @pytest.mark.parametrize("seed", range(50, 56))
 def test_boxes_with_swapped_bounds_take_the_reference_comparison_chain(ctx, oracle, seed):
     """The slab test merges the three axes with max / min when every box of the scene has
