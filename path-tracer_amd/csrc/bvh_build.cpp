@@ -307,3 +307,55 @@ bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind,
     });
     return true;
 }
+
+void ptk_collapse_bvh4(const std::vector<BvhNode>& nodes, std::vector<BvhNode4>& nodes4, int& depth4)
+{
+    nodes4.clear();
+    depth4 = 0;
+    if (nodes.empty()) return;
+    constexpr int32_t EMPTY = ~3;
+    auto pack = [](const uint16_t* q, uint32_t* box) {
+        box[0] = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
+        box[1] = (uint32_t)q[2] | ((uint32_t)q[3] << 16);
+        box[2] = (uint32_t)q[4] | ((uint32_t)q[5] << 16);
+    };
+    nodes4.reserve(nodes.size() / 2 + 2);
+    // depth-first, a node's index fixed when it is first met; (binary node, wide index, depth)
+    struct Item { int32_t bin, wide, depth; };
+    std::vector<Item> todo;
+    nodes4.emplace_back();
+    todo.push_back({0, 0, 1});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        depth4 = std::max(depth4, it.depth);
+        const BvhNode& b = nodes[(size_t)it.bin];
+        BvhNode4 w;
+        for (int s = 0; s < 4; s++) {
+            w.box[s][0] = w.box[s][1] = w.box[s][2] = 0;
+            w.child[s] = EMPTY;
+        }
+        int32_t below[4] = {-1, -1, -1, -1};   // binary node each slot continues with, if any
+        for (int c = 0; c < 2; c++) {
+            const int32_t ch = b.child[c];
+            if (ch < 0) {                       // a leaf (or nothing) keeps its own box
+                pack(b.q + 6 * c, w.box[2 * c]);
+                w.child[2 * c] = ch;
+            } else {                            // an inner node is replaced by its two children
+                const BvhNode& g = nodes[(size_t)ch];
+                for (int k = 0; k < 2; k++) {
+                    pack(g.q + 6 * k, w.box[2 * c + k]);
+                    w.child[2 * c + k] = g.child[k];
+                    if (g.child[k] >= 0) below[2 * c + k] = g.child[k];
+                }
+            }
+        }
+        for (int s = 0; s < 4; s++)
+            if (below[s] >= 0) {
+                w.child[s] = (int32_t)nodes4.size();
+                nodes4.emplace_back();
+                todo.push_back({below[s], w.child[s], it.depth + 1});
+            }
+        nodes4[(size_t)it.wide] = w;
+    }
+}

@@ -48,3 +48,8 @@ struct BvhBuild {
 // (0 sphere, 1 box, 2 rotated box).  Returns false when n is out of range or a
 // tree within the traversal stack's depth cannot be built (never for n <= 2^24).
 bool ptk_build_bvh(int n, const float* lo, const float* hi, const uint8_t* kind, BvhBuild& out);
+
+// Folds every other level of the binary tree away (layout: BvhNode4 in ptk_dev.h).  nodes4[0]
+// is the root; depth4 = nodes on the longest root-to-leaf path.  The boxes are the binary
+// nodes' own grid boxes, copied, so whatever held for them holds here.
+void ptk_collapse_bvh4(const std::vector<BvhNode>& nodes, std::vector<BvhNode4>& nodes4, int& depth4);

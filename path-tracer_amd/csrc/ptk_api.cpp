@@ -66,7 +66,7 @@ struct ptk_ctx {
     // scenes set through ptk_set_scene (device arrays, owned)
     bool big_scene = false;
     BigScene big = {};
-    void* big_alloc[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* big_alloc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool has_blur = false;
     bool ordered_boxes = true;        // every box has lo <= hi on every axis
     double big_extent = 0.0;          // what a ptk_set_scene scene's bounds were padded for
@@ -572,6 +572,8 @@ struct HostBigScene {
     std::vector<LeafRec> recs;
     std::vector<float> blo, bhi;      // padded bounds per shape
     BvhBuild bvh;
+    std::vector<BvhNode4> nodes4;     // the tree the kernels walk (every other level folded away)
+    int depth4 = 0;
     bool has_blur = false, any_dielectric = false, ordered_boxes = true;
     double build_ms = 0.0;
     double extent = 0.0;
@@ -754,6 +756,10 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     if (!ptk_build_bvh(n, blo.data(), bhi.data(), kind.data(), bvh))
         return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of depth %d exceeds the traversal stack",
                     bvh.depth);
+    ptk_collapse_bvh4(bvh.nodes, H.nodes4, H.depth4);
+    if (3 * H.depth4 > PTK_BVH4_STACK - 2)
+        return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of %d four-wide levels exceeds the traversal stack",
+                    H.depth4);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     H.build_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
     return PTK_OK;
@@ -824,6 +830,47 @@ bool check_subtree(const HostBigScene& H, int child, const uint16_t* q, std::vec
     return true;
 }
 
+// The same invariants for the four-wide tree the kernels walk: every shape in exactly one
+// leaf, with the right kind, inside the grid box of its slot; depth as the collapse reported.
+bool check_wide_tree(const HostBigScene& H, std::vector<uint8_t>& seen, int& max_depth)
+{
+    if (H.nodes4.empty()) return H.d.num_shapes == 0 || H.bvh.nodes.empty();
+    struct Item { int32_t node, depth; };
+    std::vector<Item> todo;
+    todo.push_back({0, 1});
+    const int n = H.d.num_shapes;
+    size_t visited = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.node < 0 || (size_t)it.node >= H.nodes4.size() || ++visited > H.nodes4.size()) return false;
+        max_depth = std::max(max_depth, (int)it.depth);
+        const BvhNode4& nd = H.nodes4[(size_t)it.node];
+        for (int s = 0; s < 4; s++) {
+            const int32_t ch = nd.child[s];
+            if (ch >= 0) {
+                todo.push_back({ch, it.depth + 1});
+                continue;
+            }
+            const int code = ~ch;
+            if ((code & 3) == 3) continue;                // empty slot
+            const int sh = code >> 2;
+            if (sh < 0 || sh >= n || seen[(size_t)sh]) return false;
+            seen[(size_t)sh] = 1;
+            const DevShape& o = H.shapes[(size_t)sh];
+            if ((code & 3) != (o.type == 0 ? 0 : (o.rotated ? 2 : 1))) return false;
+            const uint32_t* b = nd.box[s];
+            const uint32_t q[6] = {b[0] & 0xffffu, b[0] >> 16, b[1] & 0xffffu, b[1] >> 16, b[2] & 0xffffu, b[2] >> 16};
+            for (int k = 0; k < 3; k++) {
+                const double lo = (double)H.bvh.grid_base[k] + (double)q[k] * H.bvh.grid_scale[k];
+                const double hi = (double)H.bvh.grid_base[k] + (double)q[3 + k] * H.bvh.grid_scale[k];
+                if (H.blo[(size_t)sh * 3 + k] < lo || H.bhi[(size_t)sh * 3 + k] > hi) return false;
+            }
+        }
+    }
+    return visited == H.nodes4.size();
+}
+
 }  // namespace
 
 extern "C" {
@@ -844,6 +891,14 @@ int ptk_check_scene(const ptk_scene_desc* k, ptk_scene_stats* stats)
         if (!seen[(size_t)s]) return fail(PTK_ERR_STATE, "ptk_check_scene: shape %d is in no leaf", s);
     if (max_depth > PTK_BVH_STACK - 2 || max_depth != H.bvh.depth)
         return fail(PTK_ERR_STATE, "ptk_check_scene: depth %d (builder says %d)", max_depth, H.bvh.depth);
+    std::fill(seen.begin(), seen.end(), 0);
+    int depth4 = 0;
+    if (!check_wide_tree(H, seen, depth4))
+        return fail(PTK_ERR_STATE, "ptk_check_scene: the four-wide hierarchy is inconsistent");
+    for (int s = 0; s < n; s++)
+        if (!seen[(size_t)s]) return fail(PTK_ERR_STATE, "ptk_check_scene: shape %d is in no leaf of the four-wide hierarchy", s);
+    if (3 * depth4 > PTK_BVH4_STACK - 2 || depth4 != H.depth4)
+        return fail(PTK_ERR_STATE, "ptk_check_scene: four-wide depth %d (collapse says %d)", depth4, H.depth4);
     fill_scene_stats(H, 0, stats);
     return PTK_OK;
 }
@@ -871,14 +926,14 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     free_big_scene(c);
     c->have_scene = false;   // until the new scene is complete on the device
 
-    const void* src[7] = {bvh.nodes.data(), recs.data(), rot.data(), face_normal.data(),
-                          shapes.data(), k->mat_list, imp.data()};
-    const size_t bytes[7] = {bvh.nodes.size() * sizeof(BvhNode), recs.size() * sizeof(LeafRec),
+    const void* src[8] = {bvh.nodes.data(), recs.data(), rot.data(), face_normal.data(),
+                          shapes.data(), k->mat_list, imp.data(), H.nodes4.data()};
+    const size_t bytes[8] = {bvh.nodes.size() * sizeof(BvhNode), recs.size() * sizeof(LeafRec),
                              rot.size() * sizeof(float), face_normal.size() * sizeof(float),
                              shapes.size() * sizeof(DevShape), (size_t)k->num_mats * 6 * sizeof(float),
-                             imp.size() * sizeof(int32_t)};
+                             imp.size() * sizeof(int32_t), H.nodes4.size() * sizeof(BvhNode4)};
     uint64_t total = 0;
-    for (int i = 0; i < 7; i++) {
+    for (int i = 0; i < 8; i++) {
         hipError_t e = hipMalloc(&c->big_alloc[i], bytes[i]);
         const bool no_memory = e != hipSuccess;
         if (e == hipSuccess)
@@ -899,6 +954,7 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     c->big.shapes = (const float*)c->big_alloc[4];
     c->big.mats = (const float*)c->big_alloc[5];
     c->big.imp = (const int32_t*)c->big_alloc[6];
+    c->big.nodes4 = (const BvhNode4*)c->big_alloc[7];
     for (int i = 0; i < 3; i++) {
         c->big.grid_base[i] = bvh.grid_base[i];
         c->big.grid_scale[i] = bvh.grid_scale[i];

@@ -105,7 +105,23 @@ struct alignas(32) BvhNode {
     int32_t child[2];
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be 8 dwords");
-#define PTK_BVH_STACK 64      // traversal stack entries per lane; the builder keeps trees shallower
+#define PTK_BVH_STACK 64      // bound on the binary tree's depth (+2); the builder keeps trees shallower
+
+// What the kernels walk: the binary tree with every other level folded away.  A node holds
+// up to four children -- the children of the binary node's two children; a child that is a
+// leaf in the binary tree stays one slot -- as four boxes of six 16-bit grid coordinates
+// (three dwords per child: lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16) and four
+// child codes (node index, or ~(shape * 4 + kind) as in BvhNode; kind 3 = empty slot).
+// Slots 0, 1 come from the binary node's first child and 2, 3 from its second, so the walk
+// can keep the binary tree's order (nearer subtree first, nearer child first within it)
+// with two comparisons.  One 64-byte fetch decides four boxes and a walk makes half as many
+// dependent fetches as in the binary tree.
+struct alignas(64) BvhNode4 {
+    uint32_t box[4][3];
+    int32_t child[4];
+};
+static_assert(sizeof(BvhNode4) == 64, "BvhNode4 must be 16 dwords");
+#define PTK_BVH4_STACK 128    // traversal stack entries per lane: three per level of at most 31 levels
 
 // What a shape test reads, by shape index; a sphere needs the first 16 bytes only.
 struct alignas(16) LeafRec {
@@ -117,7 +133,8 @@ struct alignas(16) LeafRec {
 static_assert(sizeof(LeafRec) == 48, "LeafRec must be 12 dwords");
 
 struct BigScene {
-    const BvhNode* nodes;        // node 0 is the root
+    const BvhNode* nodes;        // the binary tree; node 0 is the root
+    const BvhNode4* nodes4;      // the same tree, four children per node; node 0 is the root
     const LeafRec* recs;         // [shape]
     const float* rot;            // [shape][16], as DevScene::rot
     const float* face_normal;    // [shape][7][3], as DevScene::face_normal

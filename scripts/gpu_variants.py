@@ -6,7 +6,7 @@ import os, sys
 ROOT = %r
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 import ptk
-W, H, spp = 1920, 1080, 32
+W, H, spp = 1920, 1080, 128
 ctx = ptk.Context(0)
 for scene in ("cornell_crystal", "Box_Grid", "MultiLightGlass"):
   for feats in (False, True):
