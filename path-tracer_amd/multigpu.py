@@ -259,7 +259,7 @@ def denoise_sharded(ctx, weights, n, device, variant=0, group=None, n_total=None
     y0, y1 = row_band(H, world, rank)
     den, wc = device_denoised(ctx, device)
     ctx.denoise_rows(weights, n, variant, y0, y1)       # returns when the band is written
-    if world > 1:
+    if dist.is_initialized():        # with one rank too: the same collective, gathering from itself
         gather_bands_(den.view(3, H, W), wc.view(H, W), world, rank, group)
         torch.cuda.current_stream(den.device).synchronize() if den.is_cuda else None
     return den
