@@ -134,3 +134,29 @@ def test_headless_training_epochs(tmp_path):
     assert all(np.isfinite(b).all() for b in w1)
     assert any(not np.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(w0, w1))
     assert _read_ppm(str(tmp_path / "t.ppm")).shape == (54, 96, 3)
+
+
+MULTIGPU = os.path.join(ROOT, "path-tracer_amd", "ptk_multigpu")
+
+
+@pytest.mark.parametrize("denoise", [False, True])
+def test_multi_gpu_driver_with_one_rank_writes_the_headless_image(tmp_path, denoise):
+    """ptk_multigpu is the C++ host of the several-GPU frame: samples split across ranks, one
+    exchange over RCCL (all-reduce of the colour planes, or ptk_pack_bands -> all-to-all ->
+    ptk_merge_received -> band denoise -> in-place gather).  The test box has one GPU, so this
+    runs the whole sequence with one rank -- communicator, collectives to itself, the merge
+    kernel, the band denoise -- and the image must be the headless driver's, byte for byte
+    (with one rank the merge adds nothing: the between-rank term is exactly zero)."""
+    W, H, spp = 96, 54, 12
+    base = ["--scene", scene_path("cornell_crystal"), "--res", "%dx%d" % (W, H), "--spp", str(spp)]
+    extra = ["--denoise", "2", "--weights", weights_path("BEST")] if denoise else []
+    one = str(tmp_path / "one.ppm")
+    r = subprocess.run([HEADLESS] + base + ["--counter-seeds", "--auto-exposure", "--ppm", one] + extra,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    many = str(tmp_path / "many.ppm")
+    r = subprocess.run([MULTIGPU, "--ranks", "1", "--rank", "0"] + base + ["--ppm", many] + extra,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Msamples/s" in r.stdout
+    assert open(one).read() == open(many).read()
