@@ -117,3 +117,23 @@ def test_merge_rule_is_exact_for_plain_sums_and_welford():
     assert torch.allclose(merged[:32], full[:32], rtol=1e-12, atol=1e-9)
     multigpu.refresh_std_dev(merged, n)
     assert torch.allclose(merged[32], 3 * full[16] / n, rtol=1e-12)
+
+
+def test_band_layout_of_the_c_abi_matches_the_python_partition():
+    """ptk_band_layout (the C ABI's row spans for the band exchange; needs no GPU) against
+    multigpu.row_band / band_with_halo, which the torch path uses: same spans, same longest
+    span, for even and ragged heights."""
+    sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+    import multigpu
+    import ptk
+    for H in (1, 7, 83, 90, 1080, 2160, 2161):
+        for world in (1, 2, 3, 8, 16):
+            if world > H:
+                continue
+            for halo in (0, 3, 5):
+                spans = [multigpu.band_with_halo(H, world, r, halo) for r in range(world)]
+                longest = max(b - a for a, b in spans)
+                for r in range(world):
+                    assert ptk.band_layout(H, world, r, halo) == (spans[r][0], spans[r][1], longest)
+    with pytest.raises(ptk.PtkError):
+        ptk.band_layout(100, 4, 4, 3)
