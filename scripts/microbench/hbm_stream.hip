@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void read_dword_kernel(const float* __restrict
 // and a run of rows, and per row loads 64 floats (one halo column either side) from each plane
 template <int PLANES>
 __global__ __launch_bounds__(256, 3) void read_planes_kernel(const float* __restrict__ p, int width, int rows,
-                                                             int rows_per_wave, float* out)
+                                                             int rows_per_wave, float* out, size_t plane_pad = 0)
 {
     const int strips = (width + 61) / 62, groups = (strips + 3) / 4;
     const int seg = blockIdx.x / groups, grp = blockIdx.x - seg * groups;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 3) void read_planes_kernel(const float* __rest
     if (x0 >= width) return;
     int x = x0 - 1 + (threadIdx.x & 63);
     x = x < 0 ? 0 : (x >= width ? width - 1 : x);
-    const size_t plane = (size_t)width * rows;
+    const size_t plane = (size_t)width * rows + plane_pad;
     float acc = 0.0f;
     const int y0 = seg * rows_per_wave, y1 = y0 + rows_per_wave < rows ? y0 + rows_per_wave : rows;
     for (int y = y0; y < y1; y++) {
@@ -141,6 +141,22 @@ int main()
         }
         hipFree(p);
         hipFree(out);
+    }
+    {   // the same walk with the planes a little further apart than width x rows floats: do 29
+        // streams that start at the same offset within every 16 KB collide on a channel?
+        const int W = 3840, H = 2160;
+        for (size_t pad : {(size_t)0, (size_t)64, (size_t)1024 + 64, (size_t)4096 + 192, (size_t)16384 + 448}) {
+            const size_t bytes = (size_t)29 * ((size_t)W * H + pad) * 4;
+            float *p, *out;
+            if (hipMalloc(&p, bytes) != hipSuccess || hipMalloc(&out, 4) != hipSuccess) return 1;
+            hipMemset(p, 0, bytes);
+            const int rpw = 45, segs = (H + rpw - 1) / rpw, groups = 16;
+            double t = time_ms([&] { hipLaunchKernelGGL(read_planes_kernel<29>, dim3(segs * groups), dim3(256), 0, 0, p, W, H, rpw, out, pad); }, 10);
+            printf("29 planes 3840x2160, 45 rows per wave, planes %zu floats further apart: %.0f GB/s\n", pad,
+                   (double)29 * W * H * 4 / t / 1e6);
+            hipFree(p);
+            hipFree(out);
+        }
     }
     return 0;
 }
