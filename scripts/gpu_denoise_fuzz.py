@@ -95,7 +95,11 @@ def fuzz(cases, seed, ctx=None, verbose=True, variant=0):
                        ("wcSum", r["wcSum"], wc, 5e-5)]
             floored = ("meandev", "denoised", "wcSum") + (("sd7", "mean7", "sobel") if variant == 2 else ())
             for name, got, want, tol in checks:
-                ok = rel_ok(got, want, tol, floor if name in floored else 1e-7)
+                # On a flat window the reference's 7x7 deviation is |value - mean7| with mean7 a
+                # sequential sum of 49 quotients: rounding noise of a few ulp of the value, where
+                # the shared-statistics form gives (nearly) zero.  Three floors cover it.
+                f = 3.0 * floor if (name == "sd7" and variant == 2) else floor
+                ok = rel_ok(got, want, tol, f if name in floored else 1e-7)
                 if not ok.all():
                     j = np.argwhere(~ok)[0]
                     msgs.append("N=%d %s: %d outside %g, first at %s: %r vs %r" % (
