@@ -16,7 +16,7 @@ static void usage()
     std::fprintf(stderr,
                  "usage: ptk_headless --scene FILE [--res WxH] [--spp N] [--depth D]\n"
                  "       [--rand-samp F] [--seed HEX0,HEX1 | --counter-seeds] [--fast]\n"
-                 "       [--auto-exposure] [--denoise N --weights FILE] [--device K]\n"
+                 "       [--auto-exposure] [--denoise N --weights FILE [--denoise-variant 0|2]] [--device K]\n"
                  "       [--ppm OUT.ppm] [--dump PREFIX]\n"
                  "       [--train EPOCHS --train-spp N --lr-exp X --save-weights FILE --error-log FILE]\n"
                  "         (the rendered frame becomes the target; needs --denoise N)\n");
@@ -35,7 +35,7 @@ int main(int argc, char** argv)
     int epochs = 0, train_spp = 4;
     std::string error_log;
     float lr_exp = 5.0f;
-    int W = 1536, H = 864, spp = 16, depth = 4, nwin = -1, device = 0;
+    int W = 1536, H = 864, spp = 16, depth = 4, nwin = -1, device = 0, variant = 0;
     float rand_samp = 0.005f;
     bool counter = false, fast = false, auto_exp = false, have_seed = false;
     uint64_t seed[2] = {0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull};
@@ -57,6 +57,7 @@ int main(int argc, char** argv)
         else if (a == "--auto-exposure") auto_exp = true;
         else if (a == "--denoise") nwin = std::atoi(next());
         else if (a == "--weights") weights = next();
+        else if (a == "--denoise-variant") variant = std::atoi(next());
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--ppm") ppm = next();
         else if (a == "--dump") prefix = next();
@@ -74,6 +75,7 @@ int main(int argc, char** argv)
     st.xRes = W; st.yRes = H; st.maxDepth = depth; st.randSamp = rand_samp;
     st.denoising = nwin >= 0;
     st.denoisingN = nwin >= 0 ? nwin : 1;
+    st.denoiseVariant = variant;
     st.seedMode = counter ? PTK_SEED_COUNTER : PTK_SEED_REFERENCE;
     st.mathMode = fast ? PTK_MATH_FAST : PTK_MATH_EXACT;
     if (!st.scene.LoadScene(scene)) return 1;
@@ -123,7 +125,8 @@ int main(int argc, char** argv)
         }
         st.denoiser.denoise();
         if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
-        std::printf("denoise: N=%d  %.4f ms\n", st.denoisingN, st.denoiseTime);
+        std::printf("denoise: N=%d variant %d  %.4f ms\n", st.denoisingN, st.denoiseVariant,
+                    st.denoiseTime);
         denoised = true;
     }
     st.SyncScreens();

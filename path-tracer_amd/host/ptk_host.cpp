@@ -569,7 +569,8 @@ void Denoiser::denoise()
     st_->wcSum.resize(P);
     st_->variances.resize(7 * P);
     DenoiserNN& nn = st_->denoiserNN;
-    st_->check(ptk_denoise(st_->ctx, nn.onetwo, nn.twothree, nn.threefour, st_->denoisingN, 0,
+    st_->check(ptk_denoise(st_->ctx, nn.onetwo, nn.twothree, nn.threefour, st_->denoisingN,
+                           st_->denoiseVariant,
                            st_->denoisedCol.data(), st_->wcSum.data(), st_->variances.data(),
                            nullptr),
                "ptk_denoise");

@@ -142,6 +142,9 @@ struct HostState {
     int currentRenderer = 2, denoisingBackend = 2;
     bool denoising = false;
     int denoisingN = 1;
+    // feature pass of Denoiser::denoise(): 0 = the reference's arithmetic (bit-exact against the
+    // CPU restatement), 2 = the tolerance-held pass (7x7 statistics from shared column sums)
+    int denoiseVariant = 0;
     float randSamp = 0.005f, exposure = 2.0f, g = 2.1f;
     int sampleCount = 0;
     uint64_t rayCount = 0;

@@ -102,6 +102,32 @@ def test_headless_scene_beyond_the_pod_goes_through_the_hierarchy(tmp_path):
     assert pre.mean() > 0.01
 
 
+def test_headless_tolerance_held_feature_pass(tmp_path):
+    """--denoise-variant 2 selects the feature pass that derives the 7x7 statistics from shared
+    column sums; its denoised frame stays within the tolerance of that pass (1e-3 relative on
+    the filtered colour) of the frame the reference-arithmetic pass gives, and the variant is
+    named on the timing line."""
+    W, H, spp = 192, 108, 16
+    out = {}
+    for variant in (0, 2):
+        prefix = str(tmp_path / ("v%d" % variant))
+        r = subprocess.run([HEADLESS, "--scene", scene_path("cornell_crystal"), "--res",
+                            "%dx%d" % (W, H), "--spp", str(spp), "--counter-seeds", "--denoise", "1",
+                            "--weights", weights_path("BEST"), "--denoise-variant", str(variant),
+                            "--dump", prefix], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "variant %d" % variant in r.stdout
+        out[variant] = np.fromfile(prefix + ".denoisedCol.f32", np.float32)
+    assert out[0].shape == (W * H * 3,) and np.isfinite(out[2]).all()
+    scale = np.maximum(np.abs(out[0]), 1e-2)
+    assert np.max(np.abs(out[2] - out[0]) / scale) < 1e-3
+    r = subprocess.run([HEADLESS, "--scene", scene_path("cornell_crystal"), "--res", "96x54",
+                        "--spp", "2", "--counter-seeds", "--denoise", "1", "--weights",
+                        weights_path("BEST"), "--denoise-variant", "7"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "ptk_denoise" in r.stderr
+
+
 def test_headless_rejects_bad_arguments(tmp_path):
     r = subprocess.run([HEADLESS], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
