@@ -86,6 +86,35 @@ __global__ __launch_bounds__(256, 3) void read_planes_kernel(const float* __rest
     if (acc == 12345.678f) *out = acc;
 }
 
+// the same walk with COLS adjacent columns per lane (one 4*COLS-byte load per plane and row): a
+// wave owns 64*COLS - 2 columns, so the pieces it streams are 256*COLS bytes long
+template <int PLANES, int COLS>
+__global__ __launch_bounds__(256, 2) void read_planes_wide_kernel(const float* __restrict__ p, int width, int rows,
+                                                                  int rows_per_wave, float* out)
+{
+    constexpr int OWN = 64 * COLS - 2;
+    const int strips = (width + OWN - 1) / OWN, groups = (strips + 3) / 4;
+    const int seg = blockIdx.x / groups, grp = blockIdx.x - seg * groups;
+    const int x0 = (grp * 4 + (threadIdx.x >> 6)) * OWN;
+    if (x0 >= width) return;
+    int x = x0 - 1 + (threadIdx.x & 63) * COLS;
+    x = x < 0 ? 0 : (x + COLS > width ? width - COLS : x);
+    const size_t plane = (size_t)width * rows;
+    float acc = 0.0f;
+    const int y0 = seg * rows_per_wave, y1 = y0 + rows_per_wave < rows ? y0 + rows_per_wave : rows;
+    struct __attribute__((packed, aligned(4))) Piece { float v[COLS]; };
+    for (int y = y0; y < y1; y++) {
+        Piece v[PLANES];
+#pragma unroll
+        for (int k = 0; k < PLANES; k++) v[k] = *(const Piece*)(p + (size_t)k * plane + (size_t)y * width + x);
+#pragma unroll
+        for (int k = 0; k < PLANES; k++)
+#pragma unroll
+            for (int c = 0; c < COLS; c++) acc += v[k].v[c];
+    }
+    if (acc == 12345.678f) *out = acc;
+}
+
 template <class F>
 double time_ms(F launch, int reps)
 {
@@ -138,6 +167,13 @@ int main()
             const int segs = (H + rpw - 1) / rpw, groups = 16;
             double t = time_ms([&] { hipLaunchKernelGGL(read_planes_kernel<29>, dim3(segs * groups), dim3(256), 0, 0, p, W, H, rpw, out); }, 10);
             printf("29 planes 3840x2160, strips of 62 columns, %d rows per wave (%d workgroups): %.0f GB/s\n", rpw, segs * groups, bytes / t / 1e6);
+        }
+        for (int rpw : {45, 23, 11}) {
+            const int segs = (H + rpw - 1) / rpw;
+            double t2 = time_ms([&] { hipLaunchKernelGGL((read_planes_wide_kernel<29, 2>), dim3(segs * 8), dim3(256), 0, 0, p, W, H, rpw, out); }, 10);
+            double t4 = time_ms([&] { hipLaunchKernelGGL((read_planes_wide_kernel<29, 4>), dim3(segs * 4), dim3(256), 0, 0, p, W, H, rpw, out); }, 10);
+            printf("29 planes 3840x2160, %d rows per wave: two columns per lane (strips of 126, %d workgroups) %.0f GB/s, "
+                   "four (strips of 254, %d workgroups) %.0f GB/s\n", rpw, segs * 8, bytes / t2 / 1e6, segs * 4, bytes / t4 / 1e6);
         }
         hipFree(p);
         hipFree(out);
