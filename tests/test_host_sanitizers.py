@@ -15,13 +15,17 @@ from conftest import ROOT
 
 HIPCC = "/opt/rocm/bin/hipcc"
 PKG = os.path.join(ROOT, "path-tracer_amd")
-SAN = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
-       "-Xarch_host", "-fno-sanitize-recover=undefined", "-Xarch_host", "-fno-omit-frame-pointer"]
+SAN = {"memory": (["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
+                  "-Xarch_host", "-fno-sanitize-recover=undefined", "-Xarch_host", "-fno-omit-frame-pointer"],
+                 ["-fsanitize=address", "-fsanitize=undefined", "-fno-sanitize-recover=undefined"]),
+       "thread": (["-Xarch_host", "-fsanitize=thread", "-Xarch_host", "-fno-omit-frame-pointer"],
+                  ["-fsanitize=thread"])}
 HOST_SOURCES = ["ptk_api.cpp", "bvh_build.cpp"]        # every line of host logic of libptk.so
 
 
-def _build(out_dir):
+def _build(out_dir, flavour="memory"):
     """libptk with its host translation units instrumented + the driver; returns the binary."""
+    compile_san, link_san = SAN[flavour]
     objs = []
     for name in sorted(os.listdir(os.path.join(PKG, "build"))):
         if name.endswith(".o") and name[:-2] not in HOST_SOURCES:
@@ -31,13 +35,12 @@ def _build(out_dir):
              "-fno-fast-math", "-w", "-I" + os.path.join(ROOT, "include")]
     for src in HOST_SOURCES:
         obj = os.path.join(out_dir, src + ".o")
-        subprocess.run([HIPCC] + flags + SAN + ["-x", "hip", "-c", os.path.join(PKG, "csrc", src),
+        subprocess.run([HIPCC] + flags + compile_san + ["-x", "hip", "-c", os.path.join(PKG, "csrc", src),
                                                  "-o", obj], check=True, timeout=900)
         objs.append(obj)
     exe = os.path.join(out_dir, "host_sanitize")
-    subprocess.run([HIPCC, "-O1", "-g", "-std=c++17", "--offload-arch=gfx950", "-w",
-                    "-fsanitize=address", "-fsanitize=undefined", "-fno-sanitize-recover=undefined",
-                    "-fno-gpu-sanitize", "-I" + os.path.join(ROOT, "include"),
+    subprocess.run([HIPCC, "-O1", "-g", "-std=c++17", "--offload-arch=gfx950", "-w"] + link_san +
+                   ["-fno-gpu-sanitize", "-I" + os.path.join(ROOT, "include"),
                     "-x", "c++", os.path.join(ROOT, "tests", "host_sanitize_main.cpp"),
                     os.path.join(PKG, "host", "ptk_host.cpp"), "-x", "none"] + objs + ["-o", exe],
                    check=True, timeout=900)
@@ -90,7 +93,8 @@ def sanitize_exe(tmp_path_factory):
 def _run(exe, args, tmp_path):
     env = dict(os.environ, PTK_SANITIZE_SCRATCH=str(tmp_path),
                ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0",
-               UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="4")
+               UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1:exitcode=66",
+               OMP_NUM_THREADS="4")
     return subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=env,
                           errors="replace")
 
@@ -129,3 +133,15 @@ def test_scene_tables_with_poison_are_refused_or_built(sanitize_exe, tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     assert "tables: 240 sets" in r.stdout
+
+
+def test_hierarchy_builder_threads_under_thread_sanitizer(tmp_path):
+    """The builder shares ranges of shapes between host threads above 32768 shapes (every 40th
+    table set of the driver has 40 000): the same run with ThreadSanitizer on the host code."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    exe = _build(str(tmp_path), "thread")
+    r = _run(exe, ["--tables", "80"], tmp_path)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert "tables: 80 sets" in r.stdout
