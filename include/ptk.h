@@ -169,7 +169,11 @@ typedef struct ptk_scene_stats {
  * distances, Renderers.cpp:117-213; shadow rays stopped by the lowest-index
  * opaque occluder and bent by refracting ones in index order, 490-668): the
  * shapes are tested by the same routines and the hierarchy only skips shapes a
- * ray cannot reach.  Box quaternions must be of unit length (within 1e-4).
+ * ray cannot reach -- including the unrotated boxes the reference's slab test
+ * accepts from anywhere when a plane distance is 0 / 0 (a direction component
+ * of exactly +0, the origin exactly in a face's plane; Renderers.cpp:157-196):
+ * those are looked up by coordinate.  Box quaternions must be of unit length
+ * (within 1e-4).
  * Everything else (planes, seeds, denoiser, post-process) is as after
  * ptk_set_constants.  stats is optional. */
 int ptk_set_scene(ptk_ctx* ctx, const ptk_scene_desc* scene, int want_denoise_features,

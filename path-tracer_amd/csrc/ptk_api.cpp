@@ -66,7 +66,7 @@ struct ptk_ctx {
     // scenes set through ptk_set_scene (device arrays, owned)
     bool big_scene = false;
     BigScene big = {};
-    void* big_alloc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* big_alloc[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool has_blur = false;
     bool ordered_boxes = true;        // every box has lo <= hi on every axis
     double big_extent = 0.0;          // what a ptk_set_scene scene's bounds were padded for
@@ -574,6 +574,9 @@ struct HostBigScene {
     BvhBuild bvh;
     std::vector<BvhNode4> nodes4;     // the tree the kernels walk (every other level folded away)
     int depth4 = 0;
+    std::vector<FacePlane> face_planes;   // unrotated boxes' faces: x run, y run, z run, each sorted
+    int face_plane_first[3] = {0, 0, 0}, face_plane_count[3] = {0, 0, 0};
+    float face_plane_tol = 0.0f;
     bool has_blur = false, any_dielectric = false, ordered_boxes = true;
     double build_ms = 0.0;
     double extent = 0.0;
@@ -757,6 +760,44 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
         return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of depth %d exceeds the traversal stack",
                     bvh.depth);
     ptk_collapse_bvh4(bvh.nodes, H.nodes4, H.depth4);
+    {   // ---- face planes of the unrotated boxes, sorted per axis (what for: bvh_walk).  A box
+        // test forms rp = (o - c) + c before it subtracts the planes: each of the two roundings
+        // is below 2^-24 of a coordinate difference or a coordinate, so an origin within
+        // 2^-21 * extent of a plane may be "in" it.
+        size_t boxes = 0;
+        for (int s = 0; s < n; s++) boxes += kind[(size_t)s] == 1;
+        H.face_planes.resize(boxes * 6 + 1);
+        for (int a = 0; a < 3; a++) {
+            H.face_plane_first[a] = (int)(boxes * 2 * (size_t)a);
+            H.face_plane_count[a] = (int)(boxes * 2);
+        }
+        size_t at = 0;
+        for (int s = 0; s < n; s++) {
+            if (kind[(size_t)s] != 1) continue;
+            const DevShape& o = shapes[(size_t)s];
+            for (int a = 0; a < 3; a++) {
+                FacePlane* run = H.face_planes.data() + H.face_plane_first[a];
+                run[2 * at] = {o.lo[a], s * 4 + 1};
+                run[2 * at + 1] = {o.hi[a], s * 4 + 1};
+            }
+            at++;
+        }
+        auto sort_axis = [&](int a) {
+            FacePlane* run = H.face_planes.data() + H.face_plane_first[a];
+            std::sort(run, run + H.face_plane_count[a], [](const FacePlane& x, const FacePlane& y) {
+                return x.coord < y.coord || (x.coord == y.coord && x.code < y.code);
+            });
+        };
+        if (boxes >= 16384) {
+            std::thread ty([&] { sort_axis(1); }), tz([&] { sort_axis(2); });
+            sort_axis(0);
+            ty.join();
+            tz.join();
+        } else {
+            for (int a = 0; a < 3; a++) sort_axis(a);
+        }
+        H.face_plane_tol = (float)(extent * (1.0 / 2097152.0));
+    }
     if (3 * H.depth4 > PTK_BVH4_STACK - 2)
         return fail(PTK_ERR_ARG, "ptk_set_scene: hierarchy of %d four-wide levels exceeds the traversal stack",
                     H.depth4);
@@ -899,6 +940,23 @@ int ptk_check_scene(const ptk_scene_desc* k, ptk_scene_stats* stats)
         if (!seen[(size_t)s]) return fail(PTK_ERR_STATE, "ptk_check_scene: shape %d is in no leaf of the four-wide hierarchy", s);
     if (3 * depth4 > PTK_BVH4_STACK - 2 || depth4 != H.depth4)
         return fail(PTK_ERR_STATE, "ptk_check_scene: four-wide depth %d (collapse says %d)", depth4, H.depth4);
+    // the face-plane runs: sorted, and both faces of every unrotated box on every axis
+    for (int a = 0; a < 3; a++) {
+        const FacePlane* run = H.face_planes.data() + H.face_plane_first[a];
+        std::vector<uint8_t> faces((size_t)n + 1, 0);
+        for (int i = 0; i < H.face_plane_count[a]; i++) {
+            const int s = run[i].code >> 2;
+            if (i > 0 && run[i].coord < run[i - 1].coord)
+                return fail(PTK_ERR_STATE, "ptk_check_scene: face planes of axis %d are not sorted at %d", a, i);
+            if ((run[i].code & 3) != 1 || s < 0 || s >= n || H.shapes[(size_t)s].type != 1 || H.shapes[(size_t)s].rotated ||
+                (run[i].coord != H.shapes[(size_t)s].lo[a] && run[i].coord != H.shapes[(size_t)s].hi[a]))
+                return fail(PTK_ERR_STATE, "ptk_check_scene: face plane %d of axis %d names no face of shape %d", i, a, s);
+            faces[(size_t)s]++;
+        }
+        for (int s = 0; s < n; s++)
+            if (faces[(size_t)s] != (H.shapes[(size_t)s].type == 1 && !H.shapes[(size_t)s].rotated ? 2 : 0))
+                return fail(PTK_ERR_STATE, "ptk_check_scene: shape %d has %d face planes on axis %d", s, faces[(size_t)s], a);
+    }
     fill_scene_stats(H, 0, stats);
     return PTK_OK;
 }
@@ -926,14 +984,15 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     free_big_scene(c);
     c->have_scene = false;   // until the new scene is complete on the device
 
-    const void* src[8] = {bvh.nodes.data(), recs.data(), rot.data(), face_normal.data(),
-                          shapes.data(), k->mat_list, imp.data(), H.nodes4.data()};
-    const size_t bytes[8] = {bvh.nodes.size() * sizeof(BvhNode), recs.size() * sizeof(LeafRec),
+    const void* src[9] = {bvh.nodes.data(), recs.data(), rot.data(), face_normal.data(),
+                          shapes.data(), k->mat_list, imp.data(), H.nodes4.data(), H.face_planes.data()};
+    const size_t bytes[9] = {bvh.nodes.size() * sizeof(BvhNode), recs.size() * sizeof(LeafRec),
                              rot.size() * sizeof(float), face_normal.size() * sizeof(float),
                              shapes.size() * sizeof(DevShape), (size_t)k->num_mats * 6 * sizeof(float),
-                             imp.size() * sizeof(int32_t), H.nodes4.size() * sizeof(BvhNode4)};
+                             imp.size() * sizeof(int32_t), H.nodes4.size() * sizeof(BvhNode4),
+                             H.face_planes.size() * sizeof(FacePlane)};
     uint64_t total = 0;
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 9; i++) {
         hipError_t e = hipMalloc(&c->big_alloc[i], bytes[i]);
         const bool no_memory = e != hipSuccess;
         if (e == hipSuccess)
@@ -955,6 +1014,12 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     c->big.mats = (const float*)c->big_alloc[5];
     c->big.imp = (const int32_t*)c->big_alloc[6];
     c->big.nodes4 = (const BvhNode4*)c->big_alloc[7];
+    c->big.face_planes = (const FacePlane*)c->big_alloc[8];
+    for (int i = 0; i < 3; i++) {
+        c->big.face_plane_first[i] = H.face_plane_first[i];
+        c->big.face_plane_count[i] = H.face_plane_count[i];
+    }
+    c->big.face_plane_tol = H.face_plane_tol;
     for (int i = 0; i < 3; i++) {
         c->big.grid_base[i] = bvh.grid_base[i];
         c->big.grid_scale[i] = bvh.grid_scale[i];

@@ -132,6 +132,13 @@ struct alignas(16) LeafRec {
 };
 static_assert(sizeof(LeafRec) == 48, "LeafRec must be 12 dwords");
 
+// One face of an unrotated box on one axis: the plane's coordinate and the box's leaf code.
+// Sorted by coordinate per axis (see bvh_walk in bvh_traverse.inc for what they are for).
+struct FacePlane {
+    float coord;
+    int32_t code;
+};
+
 struct BigScene {
     const BvhNode* nodes;        // the binary tree; node 0 is the root
     const BvhNode4* nodes4;      // the same tree, four children per node; node 0 is the root
@@ -141,6 +148,9 @@ struct BigScene {
     const float* shapes;         // [shape] DevShape
     const float* mats;           // [material][6]
     const int32_t* imp;          // important shapes
+    const FacePlane* face_planes; // three sorted runs: x faces, y faces, z faces
+    int32_t face_plane_first[3], face_plane_count[3];
+    float face_plane_tol;        // how far a ray origin's coordinate may lie from a plane it counts as being in
     float grid_base[3], grid_scale[3];
     int32_t any_dielectric;      // some shape's material is of type 3
     int32_t visit_all;           // every node test passes: each ray tests every shape

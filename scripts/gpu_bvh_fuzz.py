@@ -1,0 +1,144 @@
+"""Hierarchy fuzz: random scenes beyond the fixed-size limits rendered twice through
+ptk_set_scene -- with the hierarchy culling, and with PTK_SCENE_VISIT_ALL (every ray tests every
+shape, i.e. the index-order scan's candidate set) -- must give the same bits in all 38 planes and
+the same ray count.  The scenes are bent towards what could make a hierarchy skip a shape the
+scan accepts or pick another shape among equals: duplicated shapes (equal distances: the lowest
+index must win), shapes nested in one another, everything in one plane, tiny and huge extents,
+scenes far from the origin, clusters, many flat and rotated boxes, box faces in the camera's
+planes with the jitter off, glass and blur, depth 1..12.
+Usage: gpu_bvh_fuzz.py [scenes] [first_seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+import ptk       # noqa: E402
+import scenes    # noqa: E402
+
+SEED = (0x9E3779B97F4A7C15, 0xD1B54A32D192ED03)
+
+
+def bent_scene(seed, width=64, height=48):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([51, 64, 100, 257, 700, 1500, 3000]))
+    depth = int(rng.choice([1, 2, 4, 4, 4, 7, 12]))
+    extent = 12.0
+    scale = float(rng.choice([1.0, 1.0, 1.0, 1.0 / 240.0, 75.0]))
+    sc = scenes.random_scene(n, width, height, seed=seed, dielectric=bool(rng.random() < 0.6),
+                             blur=bool(rng.random() < 0.3), max_depth=depth, extent=extent,
+                             lights=int(rng.integers(1, 6)), extra_mats=int(rng.integers(0, 4)))
+    st, sm, sa = sc["shape_type"], sc["shape_mat"], sc["shape_attrs"]
+    if scale != 1.0:    # the whole scene, camera included, in millimetres or in hundreds of metres
+        sa[:, 0:3] *= np.float32(scale)
+        sa[st == 0, 3] *= np.float32(scale)
+        sa[st == 1, 3:9] *= np.float32(scale)
+        sc["cam_pos"] = (sc["cam_pos"] * np.float32(scale)).astype(np.float32)
+        extent *= scale
+    kind = int(rng.integers(0, 9))
+    body = np.arange(2, n)
+    if kind == 0:       # duplicates: equal distances at different indices, different materials
+        k = int(rng.integers(3, min(40, n - 2)))
+        src = rng.choice(body, k, replace=False)
+        dst = rng.choice(body, k, replace=False)
+        st[dst], sa[dst] = st[src], sa[src]
+    elif kind == 1:     # nested: shrink a third of the shapes into others' interiors
+        inner = rng.choice(body, len(body) // 3, replace=False)
+        outer = rng.choice(body, len(inner))
+        for i, o in zip(inner, outer):
+            c = sa[o, 0:3].copy()
+            if st[i] == 0:
+                sa[i, 0:3], sa[i, 3] = c, max(1e-4, 0.3 * (sa[o, 3] if st[o] == 0 else 0.2))
+            else:
+                h = 0.25 * np.abs(sa[i, 6:9] - sa[i, 3:6])
+                sa[i, 0:3], sa[i, 3:6], sa[i, 6:9] = c, c - h, c + h
+    elif kind == 2:     # everything in one plane: bounds degenerate along an axis
+        ax = int(rng.integers(3))
+        mid = float(np.median(sa[body, ax]))
+        shift = mid - sa[body, ax]
+        sa[body, ax] += shift
+        boxes = body[st[body] == 1]
+        off = mid - (sa[boxes, 3 + ax] + sa[boxes, 6 + ax]) / 2
+        sa[boxes, 3 + ax] += off
+        sa[boxes, 6 + ax] += off
+    elif kind == 3:     # far from the origin: large coordinates, small shapes
+        off = np.float32([rng.choice([-1, 1]) * 4000.0, 250.0, rng.choice([-1, 1]) * 3000.0])
+        sa[:, 0:3] += off
+        boxes = st == 1
+        sa[boxes, 3:6] += off
+        sa[boxes, 6:9] += off
+        sc["cam_pos"] = (sc["cam_pos"] + off).astype(np.float32)
+    elif kind == 4:     # clusters: most shapes packed into a few small regions
+        centres = rng.uniform(-0.7 * extent, 0.7 * extent, (4, 3)) + np.float32([0, 0.3 * extent, 1.4 * extent])
+        for s in body:
+            if rng.random() < 0.8:
+                c = centres[rng.integers(4)] + rng.normal(0, 0.03 * extent, 3)
+                d = (c - sa[s, 0:3]).astype(np.float32)
+                sa[s, 0:3] += d
+                if st[s] == 1:
+                    sa[s, 3:6] += d
+                    sa[s, 6:9] += d
+    elif kind == 5:     # all boxes rotated, a third of them flat
+        for s in body[st[body] == 1]:
+            sa[s, 9:13] = scenes._unit_quaternions(rng, 1)[0]
+            if rng.random() < 0.33:
+                ax = int(rng.integers(3))
+                sa[s, 3 + ax] = sa[s, 6 + ax] = sa[s, ax]
+    elif kind == 6:     # sizes over four orders of magnitude
+        for s in body:
+            f = float(10.0 ** rng.uniform(-3, 1))
+            if st[s] == 0:
+                sa[s, 3] *= f
+            else:
+                c = sa[s, 0:3].copy()
+                sa[s, 3:6] = c + (sa[s, 3:6] - c) * f
+                sa[s, 6:9] = c + (sa[s, 6:9] - c) * f
+    elif kind == 7:     # no jitter, box faces snapped into the camera's planes: camera rays of
+        # the centre column and row have an exactly zero direction component and meet 0 / 0
+        sc["rand_samp"] = 0.0
+        boxes = body[(st[body] == 1) & (sa[body, 10] == 0) & (sa[body, 11] == 0) & (sa[body, 12] == 0)]
+        for s in rng.choice(boxes, min(len(boxes), 40), replace=False):
+            ax = int(rng.integers(3))
+            face = 3 + ax if rng.random() < 0.5 else 6 + ax
+            sa[s, face] = sc["cam_pos"][ax]
+            if sa[s, 3 + ax] > sa[s, 6 + ax]:
+                sa[s, 3 + ax], sa[s, 6 + ax] = sa[s, 6 + ax], sa[s, 3 + ax]
+    # kind 8: as generated
+    # camera somewhere else now and then (inside the cloud of shapes)
+    if rng.random() < 0.3:
+        sc["cam_pos"] = (sc["cam_pos"] + np.float32([0, 0, 1.2 * extent])).astype(np.float32)
+    return sc, dict(n=n, depth=depth, scale=scale, kind=kind)
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    ctx = ptk.Context(0)
+    bad = refused = 0
+    for i, seed in enumerate(range(first, first + count)):
+        sc, what = bent_scene(seed)
+        try:
+            ctx.set_scene(sc, want_features=1)
+        except ptk.PtkError as e:       # a scene the validation refuses is not a parity case
+            refused += 1
+            print("seed %d %s refused: %s" % (seed, what, str(e)[:120]), flush=True)
+            continue
+        rays_a, _ = ctx.render(2, ptk.SEED_REFERENCE, SEED)
+        a = ctx.read_planes()
+        ctx.set_scene(sc, want_features=1, flags=ptk.SCENE_VISIT_ALL)
+        rays_b, _ = ctx.render(2, ptk.SEED_REFERENCE, SEED)
+        b = ctx.read_planes()
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        if rays_a != rays_b or not same.all():
+            bad += 1
+            print("seed %d %s: %d values differ, rays %d / %d" % (seed, what, int((~same).sum()), rays_a, rays_b),
+                  flush=True)
+        if (i + 1) % 25 == 0:
+            print("%d scenes, %d differ, %d refused" % (i + 1, bad, refused), flush=True)
+    print("%d scenes, %d differ, %d refused" % (count, bad, refused))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -80,6 +80,79 @@ def test_hierarchy_culls_nothing_the_scan_would_accept(ctx, n, dielectric, blur,
     assert np.isfinite(a[0:3]).all() and a[0:3].mean() > 0
 
 
+def _face_plane_scene(seed, shift):
+    """400 shapes, no jitter, an even frame: the camera rays of the centre column have a
+    direction whose x is exactly +0 and those of the centre row one whose y is.  Sixty small
+    boxes get a face exactly in the camera's x or y plane (shifted by `shift`), away from
+    where those rays go."""
+    import scenes
+    W, H = 64, 48
+    sc = scenes.random_scene(400, W, H, seed=seed, dielectric=True)
+    sc["rand_samp"] = 0.0
+    rng = np.random.default_rng(seed + 1)
+    st, sa = sc["shape_type"], sc["shape_attrs"]
+    cam = sc["cam_pos"]
+    picks = rng.choice(np.arange(2, 400), 60, replace=False)
+    for k, s in enumerate(picks):
+        axis = k % 2                        # x plane / y plane
+        upper = (k // 2) % 2                # the box's upper or lower face lies in it
+        c = rng.uniform([-6, -3, 3], [6, 8, 25]).astype(np.float32)
+        h = rng.uniform(0.1, 0.5, 3).astype(np.float32)
+        lo, hi = c - h, c + h
+        plane = np.float32(cam[axis] + shift)
+        if upper:
+            lo[axis], hi[axis] = plane - np.float32(0.4), plane
+        else:
+            lo[axis], hi[axis] = plane, plane + np.float32(0.4)
+        st[s] = 1
+        sa[s, :] = 0
+        sa[s, 0:3] = (lo + hi) / 2
+        sa[s, 3:6], sa[s, 6:9] = lo, hi
+        sa[s, 9] = 1.0
+        if k % 5 == 4:                      # rotated about that axis: the axis is kept
+            a = rng.uniform(0.2, 1.2)
+            sa[s, 9] = np.cos(a / 2)
+            sa[s, 10 + axis] = np.sin(a / 2)
+            sa[s, 0:3] = 0                  # ... about the origin's axis, so the plane stays put
+            sa[s, axis] = plane
+    return sc, W, H
+
+
+def test_boxes_reached_only_through_a_zero_over_zero_plane_distance(ctx, oracle):
+    """The reference's slab test divides by the direction (Renderers.cpp:157-196).  A ray whose
+    direction has an exactly zero component, starting exactly in the plane of a box face on that
+    axis, gets 0 / 0 for that plane; every comparison with the NaN fails and the test accepts the
+    box whenever the other two axes' entry and exit distances are in ascending order -- wherever
+    the box is.  An index-order scan returns such hits; a hierarchy that culls by bounds alone
+    never reaches those boxes.  The walk visits them for exactly such rays: same bits as
+    visit-all and as the CPU scan -- and the scene really has such hits, since moving the face
+    planes by 0.001 changes the centre column and row."""
+    import ptk
+    out = {}
+    for shift in (0.0, 1e-3):
+        sc, W, H = _face_plane_scene(31, shift)
+        for flags in (0, ptk.SCENE_VISIT_ALL):
+            ctx.set_scene(sc, want_features=1, flags=flags)
+            rays, _ = ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
+            out[shift, flags] = (ctx.read_planes(), rays)
+        a, b = out[shift, 0], out[shift, ptk.SCENE_VISIT_ALL]
+        assert a[1] == b[1] and _same(a[0], b[0]).all()
+    sc, W, H = _face_plane_scene(31, 0.0)
+    with oracle.variant("R"):
+        acc = oracle.new_accumulators(W, H)
+        oracle.render_scene(sc, acc, 2, 0, PIN_SEED, want_features=True, threads=8)
+    assert _same(out[0.0, 0][0], acc).all()
+    # the quirk is live: first-hit positions of the centre column / row depend on the exact planes
+    pos0 = out[0.0, 0][0][12:15].reshape(3, H, W)
+    pos1 = out[1e-3, 0][0][12:15].reshape(3, H, W)
+    moved = (np.abs(pos0 - pos1) > 0.05).any(axis=0)
+    assert moved[:, W // 2].sum() + moved[H // 2, :].sum() >= 4
+    off_axis = moved.copy()
+    off_axis[:, W // 2] = False
+    off_axis[H // 2, :] = False
+    assert off_axis.sum() <= moved[:, W // 2].sum() + moved[H // 2, :].sum()
+
+
 @pytest.mark.parametrize("n,dielectric", [(120, True), (1500, True), (1500, False)])
 def test_against_index_order_scan_on_cpu(ctx, oracle, n, dielectric):
     import ptk
