@@ -1,6 +1,7 @@
 """Random-scene parity fuzz: the check of tests/test_gpu_parity.py::test_random_scenes_... over
 many seeds (default 400).  Prints every seed whose planes differ from the restatement.
-Usage: gpu_scene_fuzz.py [scenes] [swap]   ("swap": some boxes get lo > hi on one axis)"""
+Usage: gpu_scene_fuzz.py [scenes] [swap|degenerate]   ("swap": some boxes get lo > hi on one axis;
+"degenerate": jitter off, box faces in the camera's planes, scenes far from the origin)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,11 +12,12 @@ import test_gpu_parity as T
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     swap = len(sys.argv) > 2 and sys.argv[2] == "swap"
+    degenerate = len(sys.argv) > 2 and sys.argv[2] == "degenerate"
     O.build()
     ctx = ptk.Context(0)
     bad = 0
     for seed in range(100, 100 + n):
-        r = T.random_scene_mismatch(ctx, O, seed, swap_bounds=swap)
+        r = T.random_scene_mismatch(ctx, O, seed, swap_bounds=swap, degenerate=degenerate)
         if r:
             bad += 1
             print("seed %d: %s" % (seed, r[:300]), flush=True)

@@ -665,7 +665,7 @@ def test_full_tables_fifty_shapes_fifty_materials(ctx, oracle):
     assert _mismatch_report(planes, acc_r, 48) == ""
 
 
-def random_pod_scene(O, seed, W=40, H=24, swap_bounds=False):
+def random_pod_scene(O, seed, W=40, H=24, swap_bounds=False, degenerate=False):
     """A random scene built straight into the POD: 3 to 24 shapes (axis-aligned, flat and rotated
     boxes, several snapped to a coarse grid through the origin so that slab numerators and hit
     coordinates are exact zeros; spheres), all four material kinds, blur on some, lights as
@@ -721,12 +721,46 @@ def random_pod_scene(O, seed, W=40, H=24, swap_bounds=False):
     c.num_imp = len(lights)
     for k, s in enumerate(lights):
         c.imp[k] = s
+    if degenerate:
+        _make_degenerate(c, rng)
     return c
 
 
-def random_scene_mismatch(ctx, O, seed, W=40, H=24, swap_bounds=False):
+def _make_degenerate(c, rng):
+    """Bends a POD scene towards exact zeros in the slab test: the jitter off (in an even frame
+    the camera rays of the centre column and row then have a direction component of exactly +0),
+    faces of unrotated boxes moved into the camera's planes (plane distances of 0 / 0, which the
+    reference's comparisons turn into hits on boxes the ray never touches), and now and then the
+    whole scene carried far from the origin, where `camera + offset - camera` rounds small
+    offsets to zero by itself."""
+    mode = int(rng.integers(0, 4))
+    if mode != 3:
+        c.rand_samp = 0.0
+    if mode >= 2:
+        shift = np.float32([rng.choice([-1, 1]) * 4000.0, 250.0, rng.choice([-1, 1]) * 3000.0])
+        for k in range(3):
+            c.cam_pos[k] = np.float32(c.cam_pos[k]) + shift[k]
+        for s in range(c.num_shapes):
+            off = c.shapes[s][2]
+            for k in range(3):
+                c.attrs[off + k] = np.float32(c.attrs[off + k]) + shift[k]
+                if c.shapes[s][0] == 1:
+                    c.attrs[off + 3 + k] = np.float32(c.attrs[off + 3 + k]) + shift[k]
+                    c.attrs[off + 6 + k] = np.float32(c.attrs[off + 6 + k]) + shift[k]
+    for s in range(c.num_shapes):
+        off = c.shapes[s][2]
+        if c.shapes[s][0] != 1 or c.attrs[off + 9] != 1.0 or rng.random() < 0.4:
+            continue
+        ax = int(rng.integers(0, 3))
+        lo_face = rng.random() < 0.5
+        c.attrs[off + (3 if lo_face else 6) + ax] = c.cam_pos[ax]
+        if c.attrs[off + 3 + ax] > c.attrs[off + 6 + ax]:
+            c.attrs[off + 3 + ax], c.attrs[off + 6 + ax] = c.attrs[off + 6 + ax], c.attrs[off + 3 + ax]
+
+
+def random_scene_mismatch(ctx, O, seed, W=40, H=24, swap_bounds=False, degenerate=False):
     import ptk
-    c = random_pod_scene(O, seed, W, H, swap_bounds)
+    c = random_pod_scene(O, seed, W, H, swap_bounds, degenerate)
     with O.variant("R"):
         acc = O.new_accumulators(W, H)
         n, glo, rays = O.render(c, acc, 2, 0, PIN_SEED, threads=4)
@@ -744,6 +778,14 @@ def test_random_scenes_are_bit_identical_to_the_correctly_rounded_restatement(ct
     plane of every pixel equals variant R of the restatement bit for bit, and the generator
     state matches.  scripts/gpu_scene_fuzz.py runs the same check over hundreds of seeds."""
     assert random_scene_mismatch(ctx, oracle, seed) == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_with_exact_zeros_in_the_slab_test(ctx, oracle, seed):
+    """The same bar for scenes bent towards 0 / 0 plane distances (_make_degenerate): jitter off,
+    box faces in the camera's planes, scenes 4000 units from the origin."""
+    assert random_scene_mismatch(ctx, oracle, seed, degenerate=True) == ""
 
 
 def test_reference_seeds_staged_in_row_bands_give_the_same_frame(oracle, monkeypatch):
