@@ -6,7 +6,10 @@ constant planes, large magnitudes, tiny deviations).  Discrete feature planes mu
 for bit; smooth ones, bandwidths, filtered colour and weight sums within the tolerances of
 tests/test_gpu_parity.py.  With variant 2 (the tolerance-held feature pass) the 7x7 mean and the
 Sobel magnitude are compared within a tolerance as well; primaries, per-pixel deviations, the
-"median getter" and 1/spp stay bit for bit.  Usage: gpu_denoise_fuzz.py [cases] [seed] [variant]"""
+"median getter" and 1/spp stay bit for bit.  The kind "nonfinite" (on request) sprinkles NaN and
+infinities into a frame: variant 0 must then equal the restatement as everywhere else (NaN where
+it has NaN); variant 2 may hold something else where the restatement's four smooth statistics
+are not finite, and must agree in everything downstream.  Usage: gpu_denoise_fuzz.py [cases] [seed] [variant] [kinds, e.g. nonfinite]"""
 import glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
@@ -47,13 +50,21 @@ def random_planes(rng, W, H, spp, kind):
         pl[0:16][rng.random((16, P)) < 0.1] = -0.0
     elif kind == "large":
         pl[0:16] = rng.uniform(-1, 1, (16, P)) * spp * rng.choice([1e-6, 1.0, 1e4], (16, 1))
+    elif kind == "nonfinite":        # a rendered frame's ranges with NaN and infinities sprinkled in
+        pl = random_planes(rng, W, H, spp, "frame")
+        for value in (np.nan, np.inf, -np.inf):
+            pl[0:16][rng.random((16, P)) < 0.004] = value
+        return pl
     pl[32:38] = rng.uniform(1e-4, 0.5, (6, P))
     if kind in ("flat", "zeros"):
         pl[32:38][rng.random((6, P)) < 0.3] = 0.0       # zero deviations: the 1e-6 floors decide
     return pl.astype(np.float32)
 
 
-def fuzz(cases, seed, ctx=None, verbose=True, variant=0):
+KINDS = ("noise", "frame", "flat", "zeros", "large")
+
+
+def fuzz(cases, seed, ctx=None, verbose=True, variant=0, kinds=KINDS):
     """Runs `cases` cases; returns the descriptions of those with differences."""
     exact = ((0, 15), (20, 25), (30, 36)) if variant != 2 else ((0, 10), (30, 36))
     smooth = [("sd7", 15, 20, 2e-5), ("meandev", 25, 30, 2e-5)]
@@ -69,7 +80,7 @@ def fuzz(cases, seed, ctx=None, verbose=True, variant=0):
     for i in range(cases):
         W, H = fixed[i] if i < len(fixed) else (int(rng.integers(1, 140)), int(rng.integers(1, 90)))
         spp = int(rng.choice([1, 2, 3, 7, 8, 64, 100, 128, 1000, 4097]))
-        kind = ["noise", "frame", "flat", "zeros", "large"][i % 5]
+        kind = kinds[i % len(kinds)]
         wf = weight_files[i % len(weight_files)]
         w = O.load_weights(wf)
         pl = random_planes(rng, W, H, spp, kind)
@@ -100,6 +111,12 @@ def fuzz(cases, seed, ctx=None, verbose=True, variant=0):
                 # the shared-statistics form gives (nearly) zero.  Three floors cover it.
                 f = 3.0 * floor if (name == "sd7" and variant == 2) else floor
                 ok = rel_ok(got, want, tol, f if name in floored else 1e-7)
+                if variant == 2 and kind == "nonfinite" and name in ("sd7", "mean7", "sobel", "meandev"):
+                    # the cheaper forms of these statistics reach an infinity where the reference's
+                    # order of operations meets inf - inf first, and leave out the Sobel taps of
+                    # weight zero, which the reference multiplies (0 * NaN): only the pixel's own
+                    # value has weight zero in both gradients, and that pixel is NaN downstream
+                    ok |= ~np.isfinite(want)
                 if not ok.all():
                     j = np.argwhere(~ok)[0]
                     msgs.append("N=%d %s: %d outside %g, first at %s: %r vs %r" % (
@@ -117,7 +134,8 @@ def fuzz(cases, seed, ctx=None, verbose=True, variant=0):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     bad = fuzz(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 11,
-               variant=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+               variant=int(sys.argv[3]) if len(sys.argv) > 3 else 0,
+               kinds=tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else KINDS)
     print("%d cases, %d with differences" % (cases, len(bad)))
     return 1 if bad else 0
 

@@ -16,3 +16,14 @@ def test_random_accumulators_denoise_like_the_cpu_restatement(oracle):
     import gpu_denoise_fuzz
     bad = gpu_denoise_fuzz.fuzz(30, 5, verbose=False)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_frames_with_nan_and_infinities_denoise_like_the_cpu_restatement(oracle, variant):
+    """NaN and infinities sprinkled into the accumulators (a path that divided by a zero pdf):
+    the reference-arithmetic pass equals the restatement as everywhere else, NaN where it has
+    NaN; the tolerance-held pass may differ only where the restatement's smooth statistics are
+    not finite, and equals it in bandwidths, filtered colour and weight sums."""
+    import gpu_denoise_fuzz
+    bad = gpu_denoise_fuzz.fuzz(24, 9, verbose=False, variant=variant, kinds=("nonfinite",))
+    assert not bad, "\n".join(bad)
