@@ -5,8 +5,9 @@
 // A streaming kernel: 12 B read and 12 B (+3 B) written per pixel, one pixel per
 // lane, plane-major so every access of a wave is one contiguous 256-byte run.
 // pow(v, 1/g) is exp2(log2(v) / g) on the hardware's log2 / exp2 (1 ulp each): for
-// display values in [1e-3, 10] the result is within 4e-7 relative of powf, and
-// the special cases agree (0 -> 0, negative -> NaN, inf -> inf).  The library
+// display values in [1e-3, 10] the result is within 4e-7 relative of powf (the error grows
+// with |log2 v|: 4e-6 at 1e30; results below the smallest normal number come out as zero), and
+// the special cases are powf's (see power()).  The library
 // powf, let alone a double-precision pow, made this streaming kernel
 // compute-bound (42 us at 1080p against 12 us for the bytes).
 #include <hip/hip_runtime.h>
@@ -16,6 +17,27 @@
 namespace {
 
 struct Px { float c[3]; };
+
+// powf(v, y) for the exponent of a launch (uniform): exp2(y * log2 |v|), with powf's rules for
+// what that leaves out -- a negative base gives NaN unless y is an integer (the sign then
+// follows y's parity: g = 1 passes signed planes through), -inf and -0 keep their sign for an
+// odd y and lose it otherwise, and y = 0 gives 1 for every v.
+__device__ __forceinline__ float power(float v, float y)
+{
+    if (y == 0.0f) return 1.0f;
+    const float av = __builtin_fabsf(v);
+    // the hardware logarithm reads a subnormal number as zero: scale those into range first
+    const bool tiny = av < 1.17549435e-38f;
+    const float l = __builtin_amdgcn_logf(tiny ? av * 4294967296.0f : av) - (tiny ? 32.0f : 0.0f);
+    float r = __builtin_amdgcn_exp2f(y * l);
+    if (__float_as_int(v) < 0 && v == v) {                // sign bit set, not a NaN
+        const bool y_int = y == __builtin_truncf(y);
+        const bool y_odd = y_int && __builtin_fabsf(y) < 16777216.0f && ((int)y & 1);
+        const bool keeps = y_int || av == 0.0f || av == __builtin_inff();
+        r = y_odd ? -r : (keeps ? r : __builtin_nanf(""));
+    }
+    return r;
+}
 
 __device__ __forceinline__ float source(const PostArgs& a, float n, int ch, float raw)
 {
@@ -27,7 +49,7 @@ __device__ __forceinline__ float source(const PostArgs& a, float n, int ch, floa
     default: v = 1.0f / (raw / n); break;
     }
     v = v / a.exposure;
-    return __builtin_amdgcn_exp2f(a.inv_gamma * __builtin_amdgcn_logf(v));
+    return power(v, a.inv_gamma);
 }
 
 __device__ __forceinline__ const float* source_plane(const PostArgs& a, int ch)

@@ -27,3 +27,15 @@ def test_frames_with_nan_and_infinities_denoise_like_the_cpu_restatement(oracle,
     import gpu_denoise_fuzz
     bad = gpu_denoise_fuzz.fuzz(24, 9, verbose=False, variant=variant, kinds=("nonfinite",))
     assert not bad, "\n".join(bad)
+
+
+def test_post_process_on_random_accumulators(oracle):
+    """scripts/gpu_post_process_fuzz.py: display metrics 0..6 with random exposure and gamma on
+    images of every size from 1x1 up and on values a rendered frame does not reach (negative
+    sums, which g = 1 passes through and any other gamma turns into NaN; exact zeros; subnormal,
+    tiny and huge values; NaN and infinities): float screen within 2e-6 of the restatement
+    (2e-5 beyond [1e-3, 1e3]), same class where it is not finite, 8-bit image = the quantised
+    float screen."""
+    import gpu_post_process_fuzz
+    bad = gpu_post_process_fuzz.fuzz(40, 3, verbose=False)
+    assert not bad, "\n".join(bad)
