@@ -367,7 +367,7 @@ def config5_leg(ctx, args, rank, world, gpu, device):
                                                   W, H, halo=3, ctx=ctx)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        multigpu.denoise_sharded(ctx, w, 1, device, n_total=n_total)
+        den = multigpu.denoise_sharded(ctx, w, 1, device, n_total=n_total)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         band_ms = ctx.timing().denoise_ms
@@ -383,6 +383,17 @@ def config5_leg(ctx, args, rank, world, gpu, device):
                "band_denoise_kernels_ms_rank0": band_ms,
                "merge_bytes_received_per_rank": multigpu.exchange_bytes(W, H, world, halo=3),
                "gather_bytes_received_per_rank": int((world - 1) * 16 * W * (H // world + 1))}
+    # After the clock has stopped: does every rank hold the same gathered frame?  Two checksums
+    # of the denoised frame (a plain sum and one weighted by position, so that a band in the
+    # wrong place shows), maximum and minimum over the ranks; each rank's own band is its own
+    # output, so equal frames are right frames.
+    flat = torch.nan_to_num(den.reshape(-1).double())
+    pos = (torch.arange(flat.numel(), device=flat.device) % 65521).double()
+    sums = torch.stack([flat.sum(), (flat * pos).sum()])
+    both = torch.cat([sums, -sums])
+    multigpu.all_reduce_(both, op=dist.ReduceOp.MAX)
+    out["gathered_frames_agree"] = bool((both[0] == -both[2]) and (both[1] == -both[3]))
+    out["gathered_frame_mean"] = float(both[0].item()) / flat.numel()
     return out
 
 

@@ -363,7 +363,7 @@ class Context:
     def merge_received(self, world, rank, halo, recv_ptr, recv_floats, samples_per_rank):
         """Merges the blocks received from every rank into the planes of this rank's row span
         (ptk_merge_received); the context's sample count becomes the total."""
-        n = (C.c_int * world)(*[int(x) for x in samples_per_rank])
+        n = (C.c_int * max(1, len(samples_per_rank)))(*[int(x) for x in samples_per_rank])
         self._check(self._L.ptk_merge_received(self._h, world, rank, halo, C.c_void_p(recv_ptr),
                                                C.c_size_t(recv_floats), n))
 
