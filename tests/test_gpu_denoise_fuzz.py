@@ -39,3 +39,13 @@ def test_post_process_on_random_accumulators(oracle):
     import gpu_post_process_fuzz
     bad = gpu_post_process_fuzz.fuzz(40, 3, verbose=False)
     assert not bad, "\n".join(bad)
+
+
+def test_exposure_reduce_on_random_colour_planes(oracle):
+    """scripts/gpu_exposure_fuzz.py: the three exposure formulas on images from 1x1 to beyond one
+    round of workgroups, pixel counts that are not multiples of four, negative, cancelling, huge,
+    subnormal and non-finite values: the raw sum within 1e-9 of the restatement's double sum,
+    the same class where that is not finite."""
+    import gpu_exposure_fuzz
+    bad = gpu_exposure_fuzz.fuzz(40, 3, verbose=False)
+    assert not bad, "\n".join(bad)
