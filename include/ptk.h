@@ -324,7 +324,9 @@ int ptk_band_layout(int height, int world, int rank, int halo, int* row_lo, int*
  * rank d) of each plane holding rank d's span (the rest of a block is left as it is and is
  * not read by the receiver).  send_floats >= world * 32 * rows_max * width.  The caller
  * then exchanges block d with GPU d (ncclSend/ncclRecv pairs, all_to_all_single, ...) into
- * a receive buffer of the same size.  Returns when the buffer is filled. */
+ * a receive buffer of the same size.  Returns when the buffer is filled.  The copies run
+ * on the context's own stream: whatever the caller queued on send_d on another stream (a
+ * fill, say) must have finished before the call. */
 int ptk_pack_bands(ptk_ctx* ctx, int world, int halo, float* send_d, size_t send_floats);
 
 /* Merges what the all-to-all delivered (recv_d[s]: rank s's block for this rank) into the
@@ -334,7 +336,8 @@ int ptk_pack_bands(ptk_ctx* ctx, int world, int halo, float* send_d, size_t send
  * O(ln n / n) of the reference's order-dependent one (Renderers.cpp:860-887); stdDev =
  * squared deviations / n.  samples_per_rank[world] are the samples each rank rendered; the
  * context's sample count becomes their total.  Rows outside the span keep this rank's own
- * partial sums and must not be read afterwards. */
+ * partial sums and must not be read afterwards.  The kernel runs on the context's own
+ * stream: the exchange into recv_d must have completed before the call. */
 int ptk_merge_received(ptk_ctx* ctx, int world, int rank, int halo, const float* recv_d,
                        size_t recv_floats, const int* samples_per_rank);
 

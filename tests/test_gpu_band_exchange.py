@@ -53,6 +53,7 @@ def test_band_exchange_for_any_world_size(W, H, world, halo, total):
         ctx.render(n[-1], ptk.SEED_COUNTER)
         own.append(ctx.read_planes().copy())
         buf = torch.full((world * block,), float("nan"), device=dev)   # unwritten parts stay NaN
+        torch.cuda.synchronize()        # the fill runs on torch's stream, the pack on the context's
         ctx.pack_bands(world, halo, buf.data_ptr(), buf.numel())
         torch.cuda.synchronize()
         send.append(buf)
@@ -63,6 +64,7 @@ def test_band_exchange_for_any_world_size(W, H, world, halo, total):
         lo, hi, _ = spans[r]
         # what the all-to-all delivers to rank r: block r of every rank's send buffer
         recv = torch.cat([send[s][r * block:(r + 1) * block] for s in range(world)]).contiguous()
+        torch.cuda.synchronize()
         # each block holds the sender's rows [lo, hi) of planes 0..31 and nothing else
         for s in range(world):
             blk = recv[s * block:(s + 1) * block].cpu().numpy().reshape(32, rows_max, W)
@@ -98,4 +100,55 @@ def test_band_exchange_for_any_world_size(W, H, world, halo, total):
     for bad_world, bad_rank in ((0, 0), (world, world), (world, -1), (65, 0)):
         with pytest.raises(ptk.PtkError):
             ctx.merge_received(bad_world, bad_rank, halo, buf.data_ptr(), buf.numel(), [1] * 65)
+    ctx.close()
+
+
+def test_any_row_band_of_any_frame_equals_the_whole_frame_result():
+    """ptk_denoise_rows on random bands (one row, the first and last rows, the whole frame,
+    empty) of random frames from 1x1 up, filter half-widths 0..8, both feature passes: the
+    band's rows of the filtered colour and the weight sum equal the whole-frame call bit for
+    bit and no other row is written."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+    import multigpu
+    import ptk
+    from conftest import weights_path
+    rng = np.random.default_rng(77)
+    raw_scene = scene_path("cornell_crystal")
+    w = ptk.load_weights(weights_path("BEST"))
+    ctx = ptk.Context(0)
+    dev = torch.device("cuda", 0)
+    fixed = [(1, 1), (1, 7), (7, 1), (62, 9), (63, 9), (64, 17), (125, 33)]
+    for case in range(60):
+        W, H = fixed[case] if case < len(fixed) else (int(rng.integers(1, 150)), int(rng.integers(1, 100)))
+        P = W * H
+        spp = int(rng.choice([1, 7, 64]))
+        n = int(rng.integers(0, 9))
+        variant = int(rng.choice([0, 2]))
+        raw, _, _ = ptk.scene_constants(raw_scene, W, H, 4, 0.005, True)
+        ctx.set_constants(raw)
+        pl = np.zeros((38, P), np.float32)
+        pl[0:16] = (rng.uniform(-1, 1, (16, P)) * spp).astype(np.float32)
+        pl[32:38] = rng.uniform(1e-4, 0.5, (6, P))
+        ctx.write_planes(pl, spp)
+        full = ctx.denoise(w, n, variant)
+        want = np.concatenate([full["denoised"].T, full["wcSum"].reshape(1, P)]).reshape(4, H, W)
+        den, wc = multigpu.device_denoised(ctx, dev)
+        y0 = int(rng.integers(0, H + 1))
+        y1 = int(rng.integers(y0, H + 1))
+        if case % 5 == 0:
+            y0, y1 = 0, H
+        elif case % 5 == 1 and H > 1:
+            y0, y1 = H - 1, H
+        den.fill_(-7.0)
+        wc.fill_(-7.0)
+        torch.cuda.synchronize()
+        ctx.denoise_rows(w, n, variant, y0, y1)
+        ctx.synchronize()
+        got = np.concatenate([den.cpu().numpy().reshape(3, P), wc.cpu().numpy().reshape(1, P)]).reshape(4, H, W)
+        what = "case %d: %dx%d N=%d variant %d rows [%d,%d)" % (case, W, H, n, variant, y0, y1)
+        assert np.array_equal(got[:, y0:y1].view(np.uint32), want[:, y0:y1].view(np.uint32)), what
+        outside = np.ones(H, bool)
+        outside[y0:y1] = False
+        assert (got[:, outside] == -7.0).all(), what
     ctx.close()
