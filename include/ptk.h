@@ -190,8 +190,10 @@ int ptk_check_scene(const ptk_scene_desc* scene, ptk_scene_stats* stats);
  * the scene already set by ptk_set_constants or ptk_set_scene: new camera
  * position and axes, everything else (shapes, materials, resolution, and for
  * ptk_set_scene the hierarchy) kept; the accumulators are reset.  A
- * ptk_set_scene scene pads its bounds for the extent of the scene including the
- * camera; a position beyond that extent is PTK_ERR_ARG (set the scene again). */
+ * ptk_set_scene scene is built for cameras within the bounds of its shapes and
+ * of the camera it was set with (grown by 2 % of their diagonal: the spheres'
+ * bounds are padded for the longest ray that fits); a position outside that
+ * box is PTK_ERR_ARG (set the scene again). */
 int ptk_set_camera(ptk_ctx* ctx, const float cam_pos[3], const float cam_forward[3],
                    const float cam_right[3], const float cam_up[3]);
 

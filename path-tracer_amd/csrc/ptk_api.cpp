@@ -70,6 +70,7 @@ struct ptk_ctx {
     bool has_blur = false;
     bool ordered_boxes = true;        // every box has lo <= hi on every axis
     double big_extent = 0.0;          // what a ptk_set_scene scene's bounds were padded for
+    double big_cam_lo[3] = {0, 0, 0}, big_cam_hi[3] = {0, 0, 0};   // where its camera may move
 
     float* planes_d = nullptr;        // PTK_N_PLANES * pixels
     int64_t* seeds_d = nullptr;       // seed chunk
@@ -577,6 +578,10 @@ struct HostBigScene {
     std::vector<FacePlane> face_planes;   // unrotated boxes' faces: x run, y run, z run, each sorted
     int face_plane_first[3] = {0, 0, 0}, face_plane_count[3] = {0, 0, 0};
     float face_plane_tol = 0.0f;
+    // The camera may move (ptk_set_camera) within this box without a new hierarchy: the bounds
+    // of the shapes and of the camera the scene was set with, grown by 2 % of their diagonal;
+    // the spheres' bounds are padded for the longest ray that fits it.
+    double cam_lo[3] = {0, 0, 0}, cam_hi[3] = {0, 0, 0};
     bool has_blur = false, any_dielectric = false, ordered_boxes = true;
     double build_ms = 0.0;
     double extent = 0.0;
@@ -687,25 +692,35 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     });
 
     // ---- bounds.  A shape test accepts a ray only if the ray passes the shape
-    // within the test's rounding error, which grows with the distances involved
-    // (at most 2 sqrt(3) * extent): a few 1e-7 * extent for boxes (more after a
-    // quaternion rotation); for spheres the squared miss distance is a difference
-    // of two squares of order |centre - origin|^2 <= 12 extent^2 with ~6e-7
-    // relative error, so rays passing within sqrt(r^2 + 8e-6 * extent^2) of the
-    // centre may be accepted.  The slab test against a node adds a few ulps of the
-    // same distances.  The pad below is over ten times the sum of the linear terms.
+    // within the test's rounding error, which grows with the distances involved:
+    // a few 1e-7 of the coordinates for boxes (more after a quaternion rotation),
+    // covered by the pad below, which is over ten times the sum of those linear
+    // terms and of the few ulps the slab test against a node adds.  For spheres
+    // the squared miss distance is a difference of two squares of the distance
+    // |l| from the ray's origin to the centre (Renderers.cpp:131-152): in fp32,
+    // three roundings of relative size u = 2^-24 in l.l, six in (l.d)^2 through
+    // the dot product's own three, one in the square, four for a direction that
+    // is of unit length only to 2 u -- 14 u |l|^2 < 9e-7 |l|^2 -- so rays passing
+    // within sqrt(r^2 + 9e-7 |l|^2) of the centre may be accepted.  |l| is at most
+    // the longest ray of the scene: origins are the camera and points on shapes,
+    // so the diagonal of the box that holds the shapes and the camera (grown a
+    // little, so that the camera may move: ptk_set_camera) bounds it -- not the
+    // distance of the scene from the origin.  The first pass below measures that
+    // box on unpadded spheres, the second pads them.
     const double pad = 2e-5 * extent;
     std::vector<float>& blo = H.blo;
     std::vector<float>& bhi = H.bhi;
     blo.assign((size_t)n * 3 + 3, 0.0f);
     bhi.assign((size_t)n * 3 + 3, 0.0f);
+    double sphere_margin2 = 0.0;      // 9e-7 * (longest ray)^2
+    auto bounds_pass = [&] {
     ptk_parallel_for(n, [&](int s0, int s1) {
     for (int s = s0; s < s1; s++) {
         const DevShape& o = shapes[(size_t)s];
         double lo[3], hi[3];
         if (o.type == 0) {
             const double r = std::fabs((double)o.r);
-            const double reach = std::sqrt(r * r + 8e-6 * extent * extent) + pad;
+            const double reach = std::sqrt(r * r + sphere_margin2) + pad;
             for (int i = 0; i < 3; i++) { lo[i] = o.c[i] - reach; hi[i] = o.c[i] + reach; }
         } else if (!o.rotated) {
             for (int i = 0; i < 3; i++) {
@@ -740,6 +755,27 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
         }
     }
     });
+    };
+    bounds_pass();
+    {
+        double lo[3], hi[3], diag2 = 0.0;
+        for (int i = 0; i < 3; i++) lo[i] = hi[i] = k->cam_pos[i];
+        for (int s = 0; s < n; s++)
+            for (int i = 0; i < 3; i++) {
+                lo[i] = std::min(lo[i], (double)blo[(size_t)s * 3 + i]);
+                hi[i] = std::max(hi[i], (double)bhi[(size_t)s * 3 + i]);
+            }
+        for (int i = 0; i < 3; i++) diag2 += (hi[i] - lo[i]) * (hi[i] - lo[i]);
+        const double grow = 0.02 * std::sqrt(diag2) + pad;
+        diag2 = 0.0;
+        for (int i = 0; i < 3; i++) {
+            H.cam_lo[i] = lo[i] - grow;
+            H.cam_hi[i] = hi[i] + grow;
+            diag2 += (H.cam_hi[i] - H.cam_lo[i]) * (H.cam_hi[i] - H.cam_lo[i]);
+        }
+        sphere_margin2 = 9e-7 * diag2 * 1.02;
+    }
+    bounds_pass();
     std::vector<uint8_t> kind((size_t)n + 1, 0);
     std::vector<LeafRec>& recs = H.recs;
     recs.resize((size_t)n + 1);
@@ -1021,6 +1057,10 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     }
     c->big.face_plane_tol = H.face_plane_tol;
     for (int i = 0; i < 3; i++) {
+        c->big_cam_lo[i] = H.cam_lo[i];
+        c->big_cam_hi[i] = H.cam_hi[i];
+    }
+    for (int i = 0; i < 3; i++) {
         c->big.grid_base[i] = bvh.grid_base[i];
         c->big.grid_scale[i] = bvh.grid_scale[i];
     }
@@ -1051,10 +1091,13 @@ int ptk_set_camera(ptk_ctx* c, const float* pos, const float* fwd, const float* 
         if (!std::isfinite(pos[i]) || !std::isfinite(fwd[i]) || !std::isfinite(right[i]) ||
             !std::isfinite(up[i]))
             return fail(PTK_ERR_ARG, "ptk_set_camera: component %d is not finite", i);
-        if (c->big_scene && std::fabs((double)pos[i]) > c->big_extent)
+        if (c->big_scene && (std::fabs((double)pos[i]) > c->big_extent || (double)pos[i] < c->big_cam_lo[i] ||
+                             (double)pos[i] > c->big_cam_hi[i]))
             return fail(PTK_ERR_ARG,
-                        "ptk_set_camera: position %g lies beyond the extent %g the scene's bounds "
-                        "were padded for; call ptk_set_scene again", (double)pos[i], c->big_extent);
+                        "ptk_set_camera: position %g lies outside [%g, %g] (the bounds of the scene and of the camera "
+                        "it was set with, which its hierarchy was built for); call ptk_set_scene again",
+                        (double)pos[i], std::max(c->big_cam_lo[i], -c->big_extent),
+                        std::min(c->big_cam_hi[i], c->big_extent));
     }
     int rc = bind(c);
     if (rc != PTK_OK) return rc;

@@ -282,7 +282,7 @@ def test_counter_seeds_and_statistics(ctx):
 
 def test_camera_moves_keep_the_scene(ctx):
     """ptk_set_camera: the same frame as setting the whole scene again with that camera, for
-    both kinds of scene; a position beyond the padded extent is refused."""
+    both kinds of scene; a position outside the box the hierarchy was built for is refused."""
     import os
     import ptk
     import scenes
@@ -300,8 +300,19 @@ def test_camera_moves_keep_the_scene(ctx):
     ctx.set_scene(moved, want_features=1)
     ctx.render(2, ptk.SEED_REFERENCE, PIN_SEED)
     assert _same(a, ctx.read_planes()).all()
-    with pytest.raises(ptk.PtkError, match="extent"):
+    # the hierarchy holds for cameras within the bounds of the shapes and of the camera the scene
+    # was set with (the spheres' bounds are padded for the longest ray that fits): beyond, refused
+    with pytest.raises(ptk.PtkError, match="outside"):
         ctx.set_camera(np.float32([1e4, 0, 0]), fwd, right, up)
+    top = float(moved["shape_attrs"][:, 1].max())
+    with pytest.raises(ptk.PtkError, match="outside"):
+        ctx.set_camera(np.float32([0, top + 40.0, 5.0]), fwd, right, up)
+    ctx.set_camera(np.float32([0, 0.5 * top, 5.0]), fwd, right, up)      # inside the cloud of shapes
+    ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    inside = ctx.read_planes()
+    ctx.set_scene(dict(moved, cam_pos=np.float32([0, 0.5 * top, 5.0])), want_features=1)
+    ctx.render(1, ptk.SEED_REFERENCE, PIN_SEED)
+    assert _same(inside, ctx.read_planes()).all()
 
     raw = bytearray(np.load(os.path.join(GOLDEN, "render_cornell_crystal_64x36.npz"))["constants"].tobytes())
     ctx.set_constants(bytes(raw), want_features=1)
