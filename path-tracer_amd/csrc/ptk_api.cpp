@@ -701,18 +701,18 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     // three roundings of relative size u = 2^-24 in l.l, six in (l.d)^2 through
     // the dot product's own three, one in the square, four for a direction that
     // is of unit length only to 2 u -- 14 u |l|^2 < 9e-7 |l|^2 -- so rays passing
-    // within sqrt(r^2 + 9e-7 |l|^2) of the centre may be accepted.  |l| is at most
-    // the longest ray of the scene: origins are the camera and points on shapes,
-    // so the diagonal of the box that holds the shapes and the camera (grown a
-    // little, so that the camera may move: ptk_set_camera) bounds it -- not the
-    // distance of the scene from the origin.  The first pass below measures that
-    // box on unpadded spheres, the second pads them.
+    // within sqrt(r^2 + 9e-7 |l|^2) of the centre may be accepted.  Ray origins are
+    // the camera and points on shapes, all inside the box that holds the shapes and
+    // the camera (grown a little, so that the camera may move: ptk_set_camera), so
+    // |l| is at most the distance from the sphere's centre to the farthest corner
+    // of that box -- whatever the distance of the scene from the origin.  The first
+    // pass below measures the box on unpadded spheres, the second pads them.
     const double pad = 2e-5 * extent;
     std::vector<float>& blo = H.blo;
     std::vector<float>& bhi = H.bhi;
     blo.assign((size_t)n * 3 + 3, 0.0f);
     bhi.assign((size_t)n * 3 + 3, 0.0f);
-    double sphere_margin2 = 0.0;      // 9e-7 * (longest ray)^2
+    double sphere_margin = 0.0;       // 9e-7 (and 2 % on top) once the box of ray origins is known
     auto bounds_pass = [&] {
     ptk_parallel_for(n, [&](int s0, int s1) {
     for (int s = s0; s < s1; s++) {
@@ -720,7 +720,13 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
         double lo[3], hi[3];
         if (o.type == 0) {
             const double r = std::fabs((double)o.r);
-            const double reach = std::sqrt(r * r + sphere_margin2) + pad;
+            // |l| for this sphere: from its centre to the farthest corner of the box of ray origins
+            double far2 = 0.0;
+            for (int i = 0; i < 3; i++) {
+                const double a = std::max((double)o.c[i] - H.cam_lo[i], H.cam_hi[i] - (double)o.c[i]);
+                far2 += a * a;
+            }
+            const double reach = std::sqrt(r * r + sphere_margin * far2) + pad;
             for (int i = 0; i < 3; i++) { lo[i] = o.c[i] - reach; hi[i] = o.c[i] + reach; }
         } else if (!o.rotated) {
             for (int i = 0; i < 3; i++) {
@@ -767,13 +773,11 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
             }
         for (int i = 0; i < 3; i++) diag2 += (hi[i] - lo[i]) * (hi[i] - lo[i]);
         const double grow = 0.02 * std::sqrt(diag2) + pad;
-        diag2 = 0.0;
         for (int i = 0; i < 3; i++) {
             H.cam_lo[i] = lo[i] - grow;
             H.cam_hi[i] = hi[i] + grow;
-            diag2 += (H.cam_hi[i] - H.cam_lo[i]) * (H.cam_hi[i] - H.cam_lo[i]);
         }
-        sphere_margin2 = 9e-7 * diag2 * 1.02;
+        sphere_margin = 9e-7 * 1.02;
     }
     bounds_pass();
     std::vector<uint8_t> kind((size_t)n + 1, 0);
