@@ -156,3 +156,45 @@ def test_counter_seeded_4k_split_calls_and_streams(ctx, oracle):
     assert not np.array_equal(a, b)
     ma, mb = np.nanmean(a.astype(np.float64)), np.nanmean(b.astype(np.float64))
     assert abs(ma / mb - 1.0) < 3e-3
+
+
+_RATE_SNIPPET = """
+import sys
+sys.path.insert(0, %r)
+import ptk
+W, H, spp = 1920, 1080, 64
+ctx = ptk.Context(0)
+for name in sys.argv[1:]:
+    raw, _, _ = ptk.scene_constants(name, W, H, 4, 0.005, False)
+    ctx.set_constants(raw)
+    ctx.render(4, ptk.SEED_COUNTER)
+    best = 1e30
+    for _ in range(3):
+        ctx.render(spp, ptk.SEED_COUNTER)
+        best = min(best, ctx.timing().render_ms)
+print("RATE", W * H * spp / best)
+"""
+
+
+def test_a_kernel_launched_first_does_not_size_the_grids_of_the_others():
+    """The launcher sizes each kernel's grid to one resident round of its own workgroups.  A
+    process whose first launch is a scene with blurred materials (four workgroups per compute
+    unit) must afterwards render a scene without (six) as fast as a process that only ever
+    rendered that one: the residency is looked up per kernel (one value shared by all kernels
+    cost 16 % here).  Each order runs in a process of its own, since whatever the first launch
+    leaves behind lives as long as the process."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = _RATE_SNIPPET % os.path.join(ROOT, "path-tracer_amd")
+
+    def rate(*names):
+        r = subprocess.run([sys.executable, "-c", code] + [scene_path(n) for n in names],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return float([l for l in r.stdout.splitlines() if l.startswith("RATE")][-1].split()[1])
+
+    alone = rate("cornell_crystal")
+    after = rate("MultiLightGlass", "cornell_crystal")
+    assert after > 0.93 * alone, (after, alone)
