@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void read_dword_kernel(const float* __restrict
 
 // the filter's pattern: PLANES planes of `rows` x `width` floats; a wave owns a 62-column strip
 // and a run of rows, and per row loads 64 floats (one halo column either side) from each plane
-template <int PLANES>
+template <int PLANES, bool NT = false>
 __global__ __launch_bounds__(256, 3) void read_planes_kernel(const float* __restrict__ p, int width, int rows,
                                                              int rows_per_wave, float* out, size_t plane_pad = 0)
 {
@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256, 3) void read_planes_kernel(const float* __rest
     for (int y = y0; y < y1; y++) {
         float v[PLANES];
 #pragma unroll
-        for (int k = 0; k < PLANES; k++) v[k] = p[(size_t)k * plane + (size_t)y * width + x];
+        for (int k = 0; k < PLANES; k++)
+            v[k] = NT ? __builtin_nontemporal_load(p + (size_t)k * plane + (size_t)y * width + x)
+                      : p[(size_t)k * plane + (size_t)y * width + x];
 #pragma unroll
         for (int k = 0; k < PLANES; k++) acc += v[k];
     }
@@ -165,8 +167,13 @@ int main()
         hipMemset(p, 0, bytes);
         for (int rpw : {45, 30, 23, 15}) {
             const int segs = (H + rpw - 1) / rpw, groups = 16;
-            double t = time_ms([&] { hipLaunchKernelGGL(read_planes_kernel<29>, dim3(segs * groups), dim3(256), 0, 0, p, W, H, rpw, out); }, 10);
+            double t = time_ms([&] { hipLaunchKernelGGL((read_planes_kernel<29, false>), dim3(segs * groups), dim3(256), 0, 0, p, W, H, rpw, out, (size_t)0); }, 10);
             printf("29 planes 3840x2160, strips of 62 columns, %d rows per wave (%d workgroups): %.0f GB/s\n", rpw, segs * groups, bytes / t / 1e6);
+        }
+        for (int rpw : {45, 15}) {   // the same with non-temporal loads (the planes are read once)
+            const int segs = (H + rpw - 1) / rpw, groups = 16;
+            double t = time_ms([&] { hipLaunchKernelGGL((read_planes_kernel<29, true>), dim3(segs * groups), dim3(256), 0, 0, p, W, H, rpw, out, (size_t)0); }, 10);
+            printf("29 planes 3840x2160, strips of 62 columns, %d rows per wave, non-temporal loads: %.0f GB/s\n", rpw, bytes / t / 1e6);
         }
         for (int rpw : {45, 23, 11}) {
             const int segs = (H + rpw - 1) / rpw;
@@ -187,7 +194,7 @@ int main()
             if (hipMalloc(&p, bytes) != hipSuccess || hipMalloc(&out, 4) != hipSuccess) return 1;
             hipMemset(p, 0, bytes);
             const int rpw = 45, segs = (H + rpw - 1) / rpw, groups = 16;
-            double t = time_ms([&] { hipLaunchKernelGGL(read_planes_kernel<29>, dim3(segs * groups), dim3(256), 0, 0, p, W, H, rpw, out, pad); }, 10);
+            double t = time_ms([&] { hipLaunchKernelGGL((read_planes_kernel<29, false>), dim3(segs * groups), dim3(256), 0, 0, p, W, H, rpw, out, pad); }, 10);
             printf("29 planes 3840x2160, 45 rows per wave, planes %zu floats further apart: %.0f GB/s\n", pad,
                    (double)29 * W * H * 4 / t / 1e6);
             hipFree(p);
