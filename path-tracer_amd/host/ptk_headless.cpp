@@ -86,7 +86,7 @@ int main(int argc, char** argv)
     st.renderer.Render(spp);
     if (!st.ok()) { std::fprintf(stderr, "%s\n", st.lastError.c_str()); return 1; }
     std::printf("render: %dx%d %d spp  %.3f ms  %.1f Msamples/s  %llu rays\n", W, H, spp,
-                st.renderTime, (double)W * H * spp / st.renderTime / 1e3,
+                st.renderTime, st.renderTime > 0 ? (double)W * H * spp / st.renderTime / 1e3 : 0.0,
                 (unsigned long long)st.rayCount);
     if (auto_exp) {
         st.renderer.AutoExposure();

@@ -372,6 +372,7 @@ void Renderers::UpdateConstants()
     scenePushed_ = st_->ok();
     pushedW_ = st_->xRes;
     pushedH_ = st_->yRes;
+    if (!scenePushed_) return;   // a refused scene or resolution: no host screens of that size either
     st_->check(ptk_set_math_mode(st_->ctx, st_->mathMode), "ptk_set_math_mode");
     st_->sampleCount = 0;
     st_->InitScreens();
@@ -597,7 +598,9 @@ void HostState::check(int rc, const char* what)
 
 void HostState::InitScreens()
 {
-    size_t P = (size_t)xRes * yRes;
+    // sizes the library refuses (ptk_set_constants: 1 .. 2^28 pixels) get no host screens
+    const bool valid = xRes > 0 && yRes > 0 && (int64_t)xRes * yRes <= ((int64_t)1 << 28);
+    size_t P = valid ? (size_t)xRes * yRes : 0;
     preScreen.assign(3 * P, 0.0f);
     postScreen.assign(3 * P, 0.0f);
     normal.assign(3 * P, 0.0f);
@@ -614,6 +617,7 @@ void HostState::InitScreens()
 void HostState::SyncScreens()
 {
     if (!ctx) { lastError = "SyncScreens before UpdateConstants"; return; }
+    if (xRes < 1 || yRes < 1) { lastError = "SyncScreens: no image"; return; }
     if (preScreen.size() != (size_t)3 * xRes * yRes) InitScreens();
     int sc = 0;
     check(ptk_read_accumulators(ctx, preScreen.data(), denoising ? normal.data() : nullptr,

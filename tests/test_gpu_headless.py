@@ -134,6 +134,17 @@ def test_headless_rejects_bad_arguments(tmp_path):
     r = subprocess.run([HEADLESS, "--scene", str(tmp_path / "missing.scene")], capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 1
+    # sizes and counts the library refuses end in its message and status 1, not in an abort or
+    # in host screens of that size
+    for extra, what in ((["--res", "-5x10"], "resolution"), (["--res", "0x0"], "resolution"),
+                        (["--res", "100000x100000"], "resolution"), (["--spp", "-3"], "spp"),
+                        (["--depth", "0"], "max_depth"), (["--device", "99"], "device")):
+        r = subprocess.run([HEADLESS, "--scene", scene_path("cornell")] + extra, capture_output=True,
+                           text=True, timeout=60)
+        assert r.returncode == 1 and what in r.stderr, (extra, r.returncode, r.stderr[-300:])
+    r = subprocess.run([HEADLESS, "--scene", scene_path("cornell"), "--res", "16x9", "--spp", "0"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "nan" not in r.stdout
 
 
 def test_headless_training_epochs(tmp_path):
