@@ -1,7 +1,9 @@
+"""Path-trace rate against the samples per launch, with and without features (cornell_crystal).
+Usage: gpu_spp_scan.py [width height]"""
 import os, sys
 sys.path.insert(0, "path-tracer_amd")
 import ptk
-W, H = 1920, 1080
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 ctx = ptk.Context(0)
 for feats in (False, True):
     raw, _, _ = ptk.scene_constants("data/scenes/cornell_crystal.scene", W, H, 4, 0.005, feats)
