@@ -692,10 +692,15 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     });
 
     // ---- bounds.  A shape test accepts a ray only if the ray passes the shape
-    // within the test's rounding error, which grows with the distances involved:
-    // a few 1e-7 of the coordinates for boxes (more after a quaternion rotation),
-    // covered by the pad below, which is over ten times the sum of those linear
-    // terms and of the few ulps the slab test against a node adds.  For spheres
+    // within the test's rounding error, which grows with the distances involved.
+    // For boxes it has two parts: a few 2^-24 of the distances between ray origin,
+    // box and hit point (up to 1e-6 of them after a quaternion rotation), which
+    // are at most the diagonal of the scene; and two or three units in the last
+    // place of the coordinates themselves (the test's (o - c) + c, the bounds
+    // rounded to float), which grow with the distance of the scene from the
+    // origin.  The pad covers both more than ten times over: 1e-5 of the diagonal
+    // plus 2e-6 (sixteen ulps) of the largest coordinate; the few ulps the slab
+    // test against a node adds are of the first kind.  For spheres
     // the squared miss distance is a difference of two squares of the distance
     // |l| from the ray's origin to the centre (Renderers.cpp:131-152): in fp32,
     // three roundings of relative size u = 2^-24 in l.l, six in (l.d)^2 through
@@ -707,7 +712,7 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     // |l| is at most the distance from the sphere's centre to the farthest corner
     // of that box -- whatever the distance of the scene from the origin.  The first
     // pass below measures the box on unpadded spheres, the second pads them.
-    const double pad = 2e-5 * extent;
+    double pad = 2e-5 * extent;       // for the first pass: the diagonal is at most 2 sqrt(3) extent
     std::vector<float>& blo = H.blo;
     std::vector<float>& bhi = H.bhi;
     blo.assign((size_t)n * 3 + 3, 0.0f);
@@ -772,6 +777,7 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
                 hi[i] = std::max(hi[i], (double)bhi[(size_t)s * 3 + i]);
             }
         for (int i = 0; i < 3; i++) diag2 += (hi[i] - lo[i]) * (hi[i] - lo[i]);
+        pad = std::min(pad, 1e-5 * 1.05 * std::sqrt(diag2) + 2e-6 * extent);
         const double grow = 0.02 * std::sqrt(diag2) + pad;
         for (int i = 0; i < 3; i++) {
             H.cam_lo[i] = lo[i] - grow;
