@@ -703,10 +703,12 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     // test against a node adds are of the first kind.  For spheres
     // the squared miss distance is a difference of two squares of the distance
     // |l| from the ray's origin to the centre (Renderers.cpp:131-152): in fp32,
-    // three roundings of relative size u = 2^-24 in l.l, six in (l.d)^2 through
-    // the dot product's own three, one in the square, four for a direction that
-    // is of unit length only to 2 u -- 14 u |l|^2 < 9e-7 |l|^2 -- so rays passing
-    // within sqrt(r^2 + 9e-7 |l|^2) of the centre may be accepted.  Ray origins are
+    // with u = 2^-24 for one rounding, l.l is off by up to 3 u |l|^2, (l.d)^2 by
+    // 7 u |l|^2 (the dot product's own three roundings, doubled by the square, and
+    // the square's), the difference by another u, and a direction normalised in
+    // fp32 is of unit length only to 3.5 u, which scales (l.d)^2 by up to 7 u more:
+    // 18 u |l|^2 < 1.1e-6 |l|^2 in the worst case -- so rays passing within
+    // sqrt(r^2 + 1.1e-6 |l|^2) of the centre may be accepted.  Ray origins are
     // the camera and points on shapes, all inside the box that holds the shapes and
     // the camera (grown a little, so that the camera may move: ptk_set_camera), so
     // |l| is at most the distance from the sphere's centre to the farthest corner
@@ -717,7 +719,7 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
     std::vector<float>& bhi = H.bhi;
     blo.assign((size_t)n * 3 + 3, 0.0f);
     bhi.assign((size_t)n * 3 + 3, 0.0f);
-    double sphere_margin = 0.0;       // 9e-7 (and 2 % on top) once the box of ray origins is known
+    double sphere_margin = 0.0;       // 1.1e-6 once the box of ray origins is known
     auto bounds_pass = [&] {
     ptk_parallel_for(n, [&](int s0, int s1) {
     for (int s = s0; s < s1; s++) {
@@ -783,7 +785,7 @@ int compile_big_scene(const ptk_scene_desc* k, int want_denoise_features, HostBi
             H.cam_lo[i] = lo[i] - grow;
             H.cam_hi[i] = hi[i] + grow;
         }
-        sphere_margin = 9e-7 * 1.02;
+        sphere_margin = 1.1e-6;
     }
     bounds_pass();
     std::vector<uint8_t> kind((size_t)n + 1, 0);
