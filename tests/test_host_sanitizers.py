@@ -27,6 +27,8 @@ def _build(out_dir, flavour="memory"):
     """libptk with its host translation units instrumented + the driver; returns the binary."""
     compile_san, link_san = SAN[flavour]
     objs = []
+    if not os.path.isdir(os.path.join(PKG, "build")) or len(os.listdir(os.path.join(PKG, "build"))) < 10:
+        subprocess.run(["make", "-C", PKG, "-j8", "libptk.so"], check=True, timeout=3000)   # a fresh tree
     for name in sorted(os.listdir(os.path.join(PKG, "build"))):
         if name.endswith(".o") and name[:-2] not in HOST_SOURCES:
             objs.append(os.path.join(PKG, "build", name))
