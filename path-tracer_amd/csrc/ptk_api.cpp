@@ -1081,6 +1081,7 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     }
     c->big.any_dielectric = any_dielectric ? 1 : 0;
     c->big.visit_all = (k->flags & PTK_SCENE_VISIT_ALL) ? 1 : 0;
+#if PTK_BVH_HANDOVER > 0
     if (!c->handover_stacks) {
         // one block per workgroup a launch can hold resident: at most eight of these kernels' per CU
         int cus = 0;
@@ -1095,6 +1096,7 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     }
     c->big.handover_stacks = (int32_t*)c->handover_stacks;
     c->big.handover_groups = c->handover_groups;
+#endif
     c->big_scene = true;
     c->big_extent = H.extent;
     c->has_blur = has_blur;
