@@ -6,7 +6,9 @@ scan accepts or pick another shape among equals: duplicated shapes (equal distan
 index must win), shapes nested in one another, everything in one plane, tiny and huge extents,
 scenes far from the origin, clusters, many flat and rotated boxes, box faces in the camera's
 planes with the jitter off, glass and blur, depth 1..12.
-Usage: gpu_bvh_fuzz.py [scenes] [first_seed]"""
+With "cpu" as the third argument every scene is also rendered by the CPU restatement's index-order
+scan over the same tables (correctly rounded libm variant) and must give the same bits again.
+Usage: gpu_bvh_fuzz.py [scenes] [first_seed] [cpu]"""
 import os
 import sys
 
@@ -116,6 +118,11 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     ctx = ptk.Context(0)
     bad = refused = 0
+    cpu = len(sys.argv) > 3 and sys.argv[3] == "cpu"
+    if cpu:
+        sys.path.insert(0, ROOT)
+        from oracle import oracle as O
+        O.build()
     for i, seed in enumerate(range(first, first + count)):
         sc, what = bent_scene(seed)
         try:
@@ -134,6 +141,18 @@ def main():
             bad += 1
             print("seed %d %s: %d values differ, rays %d / %d" % (seed, what, int((~same).sum()), rays_a, rays_b),
                   flush=True)
+        elif cpu:
+            with O.variant("R"):
+                acc = O.new_accumulators(sc["res_h"], sc["res_v"])
+                # (the restatement reports the rays of its last pass: two passes of one sample)
+                _, glo, r1 = O.render_scene(sc, acc, 1, 0, SEED, want_features=True, threads=16)
+                _, _, r2 = O.render_scene(sc, acc, 1, 1, glo, want_features=True, threads=16)
+                rays_c = r1 + r2
+            same = (a.view(np.uint32) == acc.view(np.uint32)) | (np.isnan(a) & np.isnan(acc))
+            if rays_a != rays_c or not same.all():
+                bad += 1
+                print("seed %d %s: %d values differ from the CPU scan, rays %d / %d" % (
+                    seed, what, int((~same).sum()), rays_a, rays_c), flush=True)
         if (i + 1) % 25 == 0:
             print("%d scenes, %d differ, %d refused" % (i + 1, bad, refused), flush=True)
     print("%d scenes, %d differ, %d refused" % (count, bad, refused))

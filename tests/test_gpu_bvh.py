@@ -352,3 +352,36 @@ def test_bad_scenes_are_rejected(ctx):
     bad["max_depth"] = 13
     with pytest.raises(ptk.PtkError, match="max_depth"):
         ctx.set_scene(bad)
+
+
+def test_scenes_bent_towards_what_could_make_a_hierarchy_skip_a_shape(ctx, oracle):
+    """scripts/gpu_bvh_fuzz.py: duplicated and nested shapes, everything in one plane, scenes in
+    millimetres, in hundreds of metres and 5000 units from the origin, clusters, flat and rotated
+    boxes, sizes over four orders of magnitude, box faces in the camera's planes with the jitter
+    off; depth 1..12, glass, blur.  Eighteen of them here (two of each kind): the hierarchy, the
+    walk that visits everything and the CPU's index-order scan give the same bits in all 38
+    planes and the same ray counts."""
+    import os
+    import sys
+    import ptk
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import gpu_bvh_fuzz as F
+    kinds = {}
+    seed = 70000
+    while len(kinds) < 9 or min(kinds.values()) < 2:
+        sc, what = F.bent_scene(seed)
+        seed += 1
+        if kinds.get(what["kind"], 0) >= 2 or what["n"] > 1500:
+            continue
+        kinds[what["kind"]] = kinds.get(what["kind"], 0) + 1
+        ctx.set_scene(sc, want_features=1)
+        rays_a, _ = ctx.render(2, ptk.SEED_REFERENCE, F.SEED)
+        a = ctx.read_planes()
+        ctx.set_scene(sc, want_features=1, flags=ptk.SCENE_VISIT_ALL)
+        rays_b, _ = ctx.render(2, ptk.SEED_REFERENCE, F.SEED)
+        assert rays_a == rays_b and _same(a, ctx.read_planes()).all(), what
+        with oracle.variant("R"):
+            acc = oracle.new_accumulators(sc["res_h"], sc["res_v"])
+            _, glo, r1 = oracle.render_scene(sc, acc, 1, 0, F.SEED, want_features=True, threads=8)
+            _, _, r2 = oracle.render_scene(sc, acc, 1, 1, glo, want_features=True, threads=8)
+        assert rays_a == r1 + r2 and _same(a, acc).all(), what
