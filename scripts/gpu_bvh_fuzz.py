@@ -8,7 +8,9 @@ scenes far from the origin, clusters, many flat and rotated boxes, box faces in 
 planes with the jitter off, glass and blur, depth 1..12.
 With "cpu" as the third argument every scene is also rendered by the CPU restatement's index-order
 scan over the same tables (correctly rounded libm variant) and must give the same bits again.
-Usage: gpu_bvh_fuzz.py [scenes] [first_seed] [cpu]"""
+A fourth argument WxHxSPP changes the frame and the samples per render from 64x48x2 (larger frames
+and more samples run as several work items per tile: chunks handed from workgroup to workgroup).
+Usage: gpu_bvh_fuzz.py [scenes] [first_seed] [cpu|gpu] [WxHxSPP]"""
 import os
 import sys
 
@@ -119,22 +121,23 @@ def main():
     ctx = ptk.Context(0)
     bad = refused = 0
     cpu = len(sys.argv) > 3 and sys.argv[3] == "cpu"
+    width, height, spp = (int(x) for x in sys.argv[4].split("x")) if len(sys.argv) > 4 else (64, 48, 2)
     if cpu:
         sys.path.insert(0, ROOT)
         from oracle import oracle as O
         O.build()
     for i, seed in enumerate(range(first, first + count)):
-        sc, what = bent_scene(seed)
+        sc, what = bent_scene(seed, width, height)
         try:
             ctx.set_scene(sc, want_features=1)
         except ptk.PtkError as e:       # a scene the validation refuses is not a parity case
             refused += 1
             print("seed %d %s refused: %s" % (seed, what, str(e)[:120]), flush=True)
             continue
-        rays_a, _ = ctx.render(2, ptk.SEED_REFERENCE, SEED)
+        rays_a, _ = ctx.render(spp, ptk.SEED_REFERENCE, SEED)
         a = ctx.read_planes()
         ctx.set_scene(sc, want_features=1, flags=ptk.SCENE_VISIT_ALL)
-        rays_b, _ = ctx.render(2, ptk.SEED_REFERENCE, SEED)
+        rays_b, _ = ctx.render(spp, ptk.SEED_REFERENCE, SEED)
         b = ctx.read_planes()
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         if rays_a != rays_b or not same.all():
@@ -145,9 +148,10 @@ def main():
             with O.variant("R"):
                 acc = O.new_accumulators(sc["res_h"], sc["res_v"])
                 # (the restatement reports the rays of its last pass: two passes of one sample)
-                _, glo, r1 = O.render_scene(sc, acc, 1, 0, SEED, want_features=True, threads=16)
-                _, _, r2 = O.render_scene(sc, acc, 1, 1, glo, want_features=True, threads=16)
-                rays_c = r1 + r2
+                rays_c, glo = 0, SEED
+                for k in range(spp):
+                    _, glo, r = O.render_scene(sc, acc, 1, k, glo, want_features=True, threads=16)
+                    rays_c += r
             same = (a.view(np.uint32) == acc.view(np.uint32)) | (np.isnan(a) & np.isnan(acc))
             if rays_a != rays_c or not same.all():
                 bad += 1
