@@ -40,6 +40,12 @@ def main():
     weights = ptk.load_weights(os.path.join(ROOT, "data", "weights", "BEST.txt"))
     c0 = ptk.Context(0)
     first = probe(c0)
+    # the kernels with the most scratch memory per lane, once, so that the runtime has sized its
+    # scratch for them before the first reading below
+    for depth in (4, 8, 12):
+        c0.set_scene(scenes.random_scene(60, 32, 32, seed=3, dielectric=True, blur=True, max_depth=depth),
+                     want_features=1)
+        c0.render(1, ptk.SEED_COUNTER)
     c0.close()
     start = used_mb()
     peak = start
