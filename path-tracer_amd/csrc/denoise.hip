@@ -22,7 +22,8 @@ namespace {
 #ifndef PTK_DN_WAVES
 #define PTK_DN_WAVES 3
 #endif
-// measurement builds: bit 0 drops the "median getter", bit 1 the 7x7 statistics
+// measurement builds: bit 0 drops the "median getter", bit 1 the 7x7 statistics; in the tolerance-held
+// form 64 drops the 7x7 statistics, 128 nine tenths of layers two and three, 256 five sixths of layer one
 #ifndef PTK_DN_ABLATE
 #define PTK_DN_ABLATE 0
 #endif
@@ -113,6 +114,9 @@ struct WaveOps {
 };
 #ifndef PTK_DN_MAD_NETWORK
 #define PTK_DN_MAD_NETWORK 1
+#endif
+#ifndef PTK_DN_FLAT_WINDOWS
+#define PTK_DN_FLAT_WINDOWS 1   // the wave-wide shortcut for flat windows in features_and_mlp
 #endif
 
 DEV float mad_procedure(float (&v)[9])
@@ -229,7 +233,10 @@ DEV void features_and_mlp(const float* t, const float* cs, int ly, int lx, const
 
         float mean7 = 0.0f;
         float ss = 0.0f;
-        if (FAST) {
+        if (FAST && (PTK_DN_ABLATE & 64)) {   // measurement build: no 7x7 statistics
+            mean7 = tk[0];
+            fk[3] = tk[1];
+        } else if (FAST) {
             // The window's seven columns each bring their mean c_i and their squared deviations
             // about it, S_i (column_stats).  Window mean = mean of the c_i; squared deviations
             // about it = sum of S_i + 7 * sum of (c_i - mean)^2, an identity in which every
@@ -311,8 +318,11 @@ DEV void features_and_mlp(const float* t, const float* cs, int ly, int lx, const
         fk[5] = md;
 
         const W2 wk = w2 + 35 * k;
+#if PTK_DN_ABLATE & 256   // measurement build: one feature group of six in the first layer
+        fk[0] += fk[2] + fk[3] + fk[4] + fk[5];
+#endif
 #pragma unroll
-        for (int g = 0; g < 6; g++)
+        for (int g = 0; g < ((PTK_DN_ABLATE & 256) ? 1 : 6); g++)
 #pragma unroll
             for (int p = 0; p < 5; p++) a1[p] = pk_fma(fk[g], wk[5 * g + p], a1[p]);
         if (features_out) {
@@ -327,20 +337,44 @@ DEV void features_and_mlp(const float* t, const float* cs, int ly, int lx, const
     // block let the scheduler interleave them.
     {
         float mad[5];
+        float win[5][9];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const float* tk = t + k * FPLANE + ly * FW + lx;
-            float win[9];
 #pragma unroll
             for (int j = 0; j < 3; j++)
 #pragma unroll
-                for (int i = 0; i < 3; i++) win[j * 3 + i] = tk[(FH - 1 + j) * FW + FH - 1 + i];
-#if PTK_DN_ABLATE & 1
-            mad[k] = win[4] + win[0] * win[8];   // measurement build: no "median getter"
-#else
-            mad[k] = mad_procedure(win);
-#endif
+                for (int i = 0; i < 3; i++) win[k][j * 3 + i] = tk[(FH - 1 + j) * FW + FH - 1 + i];
         }
+#if PTK_DN_ABLATE & 1
+#pragma unroll
+        for (int k = 0; k < 5; k++) mad[k] = win[k][4] + win[k][0] * win[k][8];   // measurement build: no "median getter"
+#elif PTK_DN_FLAT_WINDOWS
+        // Nine equal finite values give +0 (every comparison of the first pass fails or stores
+        // the value itself, so every |v - m0| is +0; checked on the host for every float), and
+        // on most surfaces the first hit's normal and albedo are the same over the whole
+        // footprint of a wave.  One branch for the wave, with both sides in one block each.
+        bool flat = true;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i != 4) flat = flat && win[k][i] == win[k][4];
+            flat = flat && (win[k][4] - win[k][4]) == 0.0f;
+        }
+        if (__builtin_amdgcn_ballot_w64(!flat) == 0) {
+            mad[0] = 0.0f;
+            mad[1] = 0.0f;
+#pragma unroll
+            for (int k = 2; k < 5; k++) mad[k] = mad_procedure(win[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) mad[k] = mad_procedure(win[k]);
+        }
+#else
+#pragma unroll
+        for (int k = 0; k < 5; k++) mad[k] = mad_procedure(win[k]);
+#endif
 #pragma unroll
         for (int k = 0; k < 5; k++) {
 #pragma unroll
@@ -366,7 +400,7 @@ DEV void features_and_mlp(const float* t, const float* cs, int ly, int lx, const
 #pragma unroll
     for (int p = 0; p < 5; p++) s3[p] = f2{0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < ((PTK_DN_ABLATE & 128) ? 1 : 10); i++)   // (measurement build: one input of ten)
 #pragma unroll
         for (int p = 0; p < 5; p++) s3[p] = pk_fma(l2[i], w2[180 + 5 * i + p], s3[p]);
 #pragma unroll
@@ -377,7 +411,7 @@ DEV void features_and_mlp(const float* t, const float* cs, int ly, int lx, const
 #pragma unroll
     for (int p = 0; p < 4; p++) s4[p] = f2{0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < ((PTK_DN_ABLATE & 128) ? 1 : 10); i++)
 #pragma unroll
         for (int p = 0; p < 4; p++) s4[p] = pk_fma(l3[i], w2[230 + 4 * i + p], s4[p]);
 #pragma unroll

@@ -67,3 +67,24 @@ def test_random_and_adversarial(oracle):
     c = rng.normal(size=(1000, 1)).astype(np.float32) * np.ones((1, 9), np.float32)
     import ptk
     assert not ptk.mad_network_host(c).any()
+
+
+def test_nine_equal_finite_values_give_plus_zero(oracle):
+    """What the feature kernels' wave-wide shortcut relies on: a window whose nine values compare
+    equal and are finite gives +0 -- the bits, not just the value -- in the literal loop and in
+    the network alike: two million random bit patterns, every power of two, the smallest and
+    largest magnitudes, and every mixture of +0 and -0 (which compare equal)."""
+    import ptk
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 1 << 32, size=2_000_000, dtype=np.uint64).astype(np.uint32)
+    vals = bits.view(np.float32)
+    vals = vals[np.isfinite(vals)]
+    powers = np.float32(2.0) ** np.arange(-149, 128, dtype=np.float32)
+    edge = np.float32([1e-45, 1.1754942e-38, 1.17549435e-38, 3.4028235e38, 1.0, 0.0])
+    vals = np.concatenate([vals, powers, -powers, edge, -edge]).astype(np.float32)
+    w = np.repeat(vals[:, None], 9, axis=1)
+    for got in (ptk.mad_network_host(w), oracle.mad_procedure(w)):
+        assert (got.view(np.uint32) == 0).all()
+    zeros = np.float32([0.0, -0.0])[np.array(list(itertools.product(range(2), repeat=9)))]
+    for got in (ptk.mad_network_host(zeros), oracle.mad_procedure(zeros)):
+        assert (got.view(np.uint32) == 0).all()
