@@ -14,7 +14,9 @@
  * Conventions: every function returns PTK_OK (0) or a negative PTK_ERR_* code
  * and leaves a message for ptk_last_error() (thread-local).  Pointers are host
  * memory unless the name ends in _d.  A context is bound to one GPU and is not
- * thread-safe; calls on one context execute in issue order.  Images are
+ * thread-safe; calls on one context execute in issue order.  Different contexts
+ * may be used from different threads at the same time, on one GPU or several
+ * (the library keeps no state that couples them).  Images are
  * row-major with row 0 at the BOTTOM (the reference's convention,
  * Renderers.cpp:67, PT.cpp:487).
  */
