@@ -67,8 +67,6 @@ struct ptk_ctx {
     bool big_scene = false;
     BigScene big = {};
     void* big_alloc[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    void* handover_stacks = nullptr;   // BigScene::handover_stacks; kept from scene to scene
-    int handover_groups = 0;
     bool has_blur = false;
     bool ordered_boxes = true;        // every box has lo <= hi on every axis
     double big_extent = 0.0;          // what a ptk_set_scene scene's bounds were padded for
@@ -511,7 +509,6 @@ int ptk_destroy(ptk_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_image_buffers(c);
     free_big_scene(c);
-    (void)hipFree(c->handover_stacks);
     (void)hipFree(c->scene_d);
     (void)hipFree(c->rays_d);
     (void)hipFree(c->sum_d);
@@ -1081,22 +1078,6 @@ int ptk_set_scene(ptk_ctx* c, const ptk_scene_desc* k, int want_denoise_features
     }
     c->big.any_dielectric = any_dielectric ? 1 : 0;
     c->big.visit_all = (k->flags & PTK_SCENE_VISIT_ALL) ? 1 : 0;
-#if PTK_BVH_HANDOVER > 0
-    if (!c->handover_stacks) {
-        // one block per workgroup a launch can hold resident: at most eight of these kernels' per CU
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        c->handover_groups = 8 * (cus > 0 ? cus : 1);
-        hipError_t e = hipMalloc(&c->handover_stacks, (size_t)c->handover_groups * PTK_HANDOVER_STACK_INTS * sizeof(int32_t));
-        if (e != hipSuccess) {
-            c->handover_stacks = nullptr;
-            free_big_scene(c);
-            return fail(PTK_ERR_NOMEM, "ptk_set_scene: handover stacks: %s", hipGetErrorString(e));
-        }
-    }
-    c->big.handover_stacks = (int32_t*)c->handover_stacks;
-    c->big.handover_groups = c->handover_groups;
-#endif
     c->big_scene = true;
     c->big_extent = H.extent;
     c->has_blur = has_blur;

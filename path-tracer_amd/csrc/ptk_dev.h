@@ -122,13 +122,6 @@ struct alignas(64) BvhNode4 {
 };
 static_assert(sizeof(BvhNode4) == 64, "BvhNode4 must be 16 dwords");
 #define PTK_BVH4_STACK 128    // traversal stack entries per lane: three per level of at most 31 levels
-#define PTK_HANDOVER_STACK_INTS (PTK_BVH4_STACK * 64)   // see BigScene::handover_stacks
-// Measurement builds of the whole library (the kernels and ptk_set_scene both read it): a wave
-// of the hierarchy kernels hands its last walking lanes, this many or fewer, to one wave of its
-// workgroup (closest_hit_shared in bvh_traverse.inc).  0: never.
-#ifndef PTK_BVH_HANDOVER
-#define PTK_BVH_HANDOVER 0
-#endif
 
 // What a shape test reads, by shape index; a sphere needs the first 16 bytes only.
 struct alignas(16) LeafRec {
@@ -161,11 +154,6 @@ struct BigScene {
     float grid_base[3], grid_scale[3];
     int32_t any_dielectric;      // some shape's material is of type 3
     int32_t visit_all;           // every node test passes: each ray tests every shape
-    // Device memory through which the waves of a workgroup hand the stacks of unfinished walks
-    // to one another: handover_groups blocks of PTK_HANDOVER_STACK_INTS ints, one per resident
-    // workgroup of a launch (indexed by blockIdx.x).
-    int32_t* handover_stacks;
-    int32_t handover_groups;
 };
 
 struct RenderArgs {
